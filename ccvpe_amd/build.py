@@ -1,0 +1,74 @@
+"""Build libccvpe_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m ccvpe_amd.build [--force]
+
+The .so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libccvpe_hip.so")
+STAMP = os.path.join(CSRC, ".libccvpe_hip.stamp")
+SOURCES = ["ccvpe_api.hip", "kernels_igemm.hip", "kernels_encoder.hip", "kernels_match.hip", "kernels_tail.hip"]
+HEADERS = ["kernels.h", os.path.join("..", "..", "include", "ccvpe.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
+        with open(STAMP) as fh:
+            if fh.read().strip() == dig:
+                return LIB
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if out.strip() and verbose:
+            print(out)
+        if p.returncode != 0:
+            failed = True
+            print(f"hipcc failed on {src}:\n{out}", file=sys.stderr)
+    if failed:
+        raise RuntimeError("hipcc compilation failed")
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(STAMP, "w") as fh:
+        fh.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

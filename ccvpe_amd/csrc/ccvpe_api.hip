@@ -1,0 +1,1025 @@
+// C ABI of libccvpe_hip.so: handle, state_dict ingestion (BN folding + weight packing), execution
+// plan with lifetime-based workspace reuse, forward orchestration.  See include/ccvpe.h.
+//
+// The orchestration restates CVM_*.forward (reference models.py:150-343, 448-652, 752-950, 1051-1244)
+// as a static list of kernel launches over NHWC tensors; concatenations are channel-offset writes
+// into pre-allocated buffers, the encoder taps are written by the producing GEMM's epilogue.
+#include "../../include/ccvpe.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+using namespace ccvpe;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) return fail(CCVPE_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// static description of the network (mirrors ccvpe_amd/spec.py; reference lines cited there)
+// ------------------------------------------------------------------------------------------------
+struct BlockSpec { int e, k, s, cin, cout; };
+static const BlockSpec B0[16] = {
+    {1, 3, 1, 32, 16}, {6, 3, 2, 16, 24}, {6, 3, 1, 24, 24}, {6, 5, 2, 24, 40}, {6, 5, 1, 40, 40},
+    {6, 3, 2, 40, 80}, {6, 3, 1, 80, 80}, {6, 3, 1, 80, 80}, {6, 5, 1, 80, 112}, {6, 5, 1, 112, 112},
+    {6, 5, 1, 112, 112}, {6, 5, 2, 112, 192}, {6, 5, 1, 192, 192}, {6, 5, 1, 192, 192}, {6, 5, 1, 192, 192},
+    {6, 3, 1, 192, 320},
+};
+static const int TAP_BLOCK[5] = {15, 10, 4, 2, 0};   // skip of decoder level 6..2 (models.py:465-469)
+static const float BN_EPS = 1e-3f;                   // utils.py:666
+
+struct DecLevel { int din, dout, skip, mid, out; };
+struct VariantSpec {
+    int feat_h;
+    int head_ch[6];
+    int sat_desc;
+    int match_ch[6];
+    int step[6];
+    int n_rolls;
+    int centre;
+    DecLevel loc[6], ori[6];
+};
+static const DecLevel VIGOR_LOC[6] = {{1281, 1024, 320, 640, 640}, {641, 320, 112, 320, 320}, {321, 160, 40, 160, 160},
+                                      {161, 80, 24, 80, 80},       {81, 40, 16, 40, 40},      {41, 16, 0, 16, 1}};
+static const DecLevel VIGOR_ORI[6] = {{1300, 1024, 320, 640, 640}, {640, 256, 112, 256, 256}, {256, 128, 40, 128, 128},
+                                      {128, 64, 24, 64, 64},       {64, 32, 16, 32, 32},      {32, 16, 0, 16, 2}};
+static const DecLevel KITTI_LOC[6] = {{2049, 1024, 320, 512, 512}, {513, 256, 112, 256, 256}, {257, 128, 40, 128, 128},
+                                      {129, 64, 24, 128, 128},     {129, 32, 16, 32, 32},     {33, 16, 0, 16, 1}};
+static const DecLevel KITTI_ORI[6] = {{2064, 1024, 320, 512, 512}, {512, 256, 112, 256, 256}, {256, 128, 40, 128, 128},
+                                      {128, 64, 24, 64, 64},       {64, 32, 16, 32, 32},      {32, 16, 0, 16, 2}};
+
+static VariantSpec make_variant(int v) {
+    VariantSpec s{};
+    auto cp = [](DecLevel* d, const DecLevel* src) { for (int i = 0; i < 6; ++i) d[i] = src[i]; };
+    if (v == CCVPE_VARIANT_KITTI) {
+        s.feat_h = 8;
+        int hc[6] = {16, 8, 4, 2, 1, 1}, mc[6] = {2048, 512, 256, 128, 128, 32}, st[6] = {128, 64, 32, 16, 8, 8};
+        for (int i = 0; i < 6; ++i) { s.head_ch[i] = hc[i]; s.match_ch[i] = mc[i]; s.step[i] = st[i]; }
+        s.sat_desc = 2048; s.n_rolls = 16; s.centre = 0;
+        cp(s.loc, KITTI_LOC); cp(s.ori, KITTI_ORI);
+    } else {
+        int mc[6] = {1280, 640, 320, 160, 80, 40}, st[6] = {64, 32, 16, 8, 4, 2};
+        int hv[6] = {64, 32, 16, 8, 4, 2}, ho[6] = {32, 16, 8, 4, 2, 1};
+        for (int i = 0; i < 6; ++i) {
+            s.match_ch[i] = mc[i]; s.step[i] = st[i];
+            s.head_ch[i] = (v == CCVPE_VARIANT_OXFORD) ? ho[i] : hv[i];
+        }
+        s.feat_h = (v == CCVPE_VARIANT_OXFORD) ? 4 : 10;
+        s.sat_desc = 1280; s.n_rolls = 20; s.centre = (v == CCVPE_VARIANT_OXFORD);
+        cp(s.loc, VIGOR_LOC); cp(s.ori, VIGOR_ORI);
+    }
+    return s;
+}
+
+static void static_pad(int k, int s, int& lo, int& hi) {   // utils.py:261-277 with the nominal-224 walk
+    if (s == 1) { lo = hi = (k - 1) / 2; return; }
+    int total = k - 2;
+    lo = total / 2; hi = total - lo;
+}
+static int conv_out(int n, int k, int s) {
+    int lo, hi; static_pad(k, s, lo, hi);
+    return (n + lo + hi - k) / s + 1;
+}
+static int se_squeeze(int cin) { return std::max(1, (int)(cin * 0.25)); }   // model.py:79
+static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+struct PackedConv {
+    float* w = nullptr;
+    float* bias = nullptr;
+    int N = 0, Kpad = 0, nchunks = 0, cinp = 0, KH = 1, KW = 1;
+};
+struct BlockW {
+    PackedConv expand, project;
+    float *dw_w = nullptr, *dw_b = nullptr, *se_w1 = nullptr, *se_b1 = nullptr, *se_w2 = nullptr, *se_b2 = nullptr;
+    int sq = 0;
+};
+struct EncoderW {
+    float *stem_w = nullptr, *stem_b = nullptr;
+    BlockW blk[16];
+    PackedConv head;
+};
+struct DecoderW {
+    PackedConv deconv[6], conva[6], convb[5];
+    float* tail_w = nullptr;
+    float tail_b[2] = {0.f, 0.f};
+};
+
+struct Tensor { int id = -1; int B = 0, H = 0, W = 0, C = 0; };
+
+struct Ctx {
+    float* arena = nullptr;
+    const std::vector<size_t>* off = nullptr;
+    hipStream_t stream = nullptr;
+    const float* grd = nullptr;
+    const float* sat = nullptr;
+    ccvpe_outputs out{};
+    float* ptr(const Tensor& t) const { return arena + (*off)[t.id]; }
+};
+
+struct Op {
+    std::string name;
+    std::function<void(const Ctx&)> fn;
+    std::vector<int> uses;
+    double flops = 0, bytes = 0;
+};
+
+struct TapInfo { Tensor t; int coff; int C; };
+
+struct Plan {
+    int B = 0, gh = 0, gw = 0;
+    bool debug = false;
+    std::vector<size_t> size;     // floats per tensor
+    std::vector<size_t> off;      // float offset in the arena
+    std::vector<Op> ops;
+    std::map<std::string, TapInfo> taps;
+    size_t total = 0;             // floats
+    float* arena = nullptr;
+
+    Tensor alloc(int B_, int H, int W, int C) {
+        Tensor t; t.id = (int)size.size(); t.B = B_; t.H = H; t.W = W; t.C = C;
+        size.push_back((size_t)B_ * H * W * C);
+        return t;
+    }
+    void add(const std::string& name, std::vector<Tensor> uses, std::function<void(const Ctx&)> fn, double flops = 0, double bytes = 0) {
+        Op o; o.name = name; o.fn = std::move(fn); o.flops = flops; o.bytes = bytes;
+        for (auto& t : uses) o.uses.push_back(t.id);
+        ops.push_back(std::move(o));
+    }
+    void assign() {
+        const int n = (int)size.size();
+        std::vector<int> first(n, 1 << 30), last(n, -1);
+        for (int i = 0; i < (int)ops.size(); ++i)
+            for (int id : ops[i].uses) { first[id] = std::min(first[id], i); last[id] = std::max(last[id], i); }
+        if (debug) for (int i = 0; i < n; ++i) last[i] = 1 << 30;
+        off.assign(n, 0);
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
+        std::vector<int> placed;
+        total = 0;
+        for (int id : order) {
+            if (last[id] < 0) continue;   // never used
+            const size_t sz = (size[id] + 63) & ~(size_t)63;   // 256-byte granules
+            // candidate offsets: 0 and the end of every live, lifetime-overlapping tensor
+            std::vector<std::pair<size_t, size_t>> busy;
+            for (int o : placed)
+                if (!(last[o] < first[id] || last[id] < first[o])) busy.push_back({off[o], off[o] + ((size[o] + 63) & ~(size_t)63)});
+            std::sort(busy.begin(), busy.end());
+            size_t pos = 0;
+            for (auto& iv : busy) {
+                if (pos + sz <= iv.first) break;
+                pos = std::max(pos, iv.second);
+            }
+            off[id] = pos;
+            total = std::max(total, pos + sz);
+            placed.push_back(id);
+        }
+    }
+};
+
+struct ccvpe_handle_s {
+    ccvpe_config cfg{};
+    VariantSpec vs{};
+    int rolls[6] = {0};                               // R_k of the ms outputs
+    std::map<std::string, std::vector<int64_t>> expect;   // key -> shape
+    std::map<std::string, std::vector<float>> host;       // raw host copies until finalize
+    std::set<std::string> skipped;
+    bool finalized = false;
+    bool debug = false;
+    std::vector<void*> dev_allocs;
+    EncoderW grd_enc, sat_enc;
+    PackedConv grd_heads, sat_desc;
+    float* grd_wh[6] = {nullptr};
+    float grd_b2[6] = {0};
+    DecoderW loc, ori;
+    std::vector<std::unique_ptr<Plan>> plans;
+    float* arena = nullptr;
+    size_t arena_floats = 0;
+    // profiling rows of the last ccvpe_profile_forward
+    struct Row { std::string name; float ms; double flops, bytes; };
+    std::vector<Row> prof;
+};
+
+// ---- expected state_dict layout -----------------------------------------------------------------
+static void add_bn(std::map<std::string, std::vector<int64_t>>& m, const std::string& p, int c) {
+    m[p + ".weight"] = {c}; m[p + ".bias"] = {c}; m[p + ".running_mean"] = {c}; m[p + ".running_var"] = {c};
+    m[p + ".num_batches_tracked"] = {};
+}
+static void add_encoder(std::map<std::string, std::vector<int64_t>>& m, const std::string& p) {
+    m[p + "._conv_stem.weight"] = {32, 3, 3, 3};
+    add_bn(m, p + "._bn0", 32);
+    for (int i = 0; i < 16; ++i) {
+        const BlockSpec& b = B0[i];
+        std::string q = p + "._blocks." + std::to_string(i);
+        int mid = b.cin * b.e;
+        if (b.e != 1) { m[q + "._expand_conv.weight"] = {mid, b.cin, 1, 1}; add_bn(m, q + "._bn0", mid); }
+        m[q + "._depthwise_conv.weight"] = {mid, 1, b.k, b.k};
+        add_bn(m, q + "._bn1", mid);
+        int sq = se_squeeze(b.cin);
+        m[q + "._se_reduce.weight"] = {sq, mid, 1, 1}; m[q + "._se_reduce.bias"] = {sq};
+        m[q + "._se_expand.weight"] = {mid, sq, 1, 1}; m[q + "._se_expand.bias"] = {mid};
+        m[q + "._project_conv.weight"] = {b.cout, mid, 1, 1};
+        add_bn(m, q + "._bn2", b.cout);
+    }
+    m[p + "._conv_head.weight"] = {1280, 320, 1, 1};
+    add_bn(m, p + "._bn1", 1280);
+    m[p + "._fc.weight"] = {1000, 1280};
+    m[p + "._fc.bias"] = {1000};
+}
+static void build_expect(ccvpe_handle_s* h) {
+    auto& m = h->expect;
+    add_encoder(m, "grd_efficientnet");
+    add_encoder(m, "sat_efficientnet");
+    for (int k = 0; k < 6; ++k) {
+        std::string p = "grd_feature_to_descriptor" + std::to_string(k + 1);
+        m[p + ".0.weight"] = {h->vs.head_ch[k], 1280, 1, 1}; m[p + ".0.bias"] = {h->vs.head_ch[k]};
+        m[p + ".2.weight"] = {1, h->vs.feat_h, 1, 1};        m[p + ".2.bias"] = {1};
+    }
+    m["sat_feature_to_descriptors.1.weight"] = {h->vs.sat_desc, 5120};
+    m["sat_feature_to_descriptors.1.bias"] = {h->vs.sat_desc};
+    for (int d = 0; d < 2; ++d) {
+        const DecLevel* lv = d ? h->vs.ori : h->vs.loc;
+        std::string sfx = d ? "_ori" : "";
+        for (int j = 0; j < 6; ++j) {
+            std::string n = std::to_string(6 - j);
+            m["deconv" + n + sfx + ".weight"] = {lv[j].din, lv[j].dout, 2, 2};
+            m["deconv" + n + sfx + ".bias"] = {lv[j].dout};
+            m["conv" + n + sfx + ".0.weight"] = {lv[j].mid, lv[j].dout + lv[j].skip, 3, 3};
+            m["conv" + n + sfx + ".0.bias"] = {lv[j].mid};
+            m["conv" + n + sfx + ".2.weight"] = {lv[j].out, lv[j].mid, 3, 3};
+            m["conv" + n + sfx + ".2.bias"] = {lv[j].out};
+        }
+    }
+}
+
+// ---- upload helpers ------------------------------------------------------------------------------
+static int upload(ccvpe_handle_s* h, const std::vector<float>& v, float** out) {
+    void* d = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 4) * sizeof(float);
+    HIPCHK(hipMalloc(&d, bytes));
+    h->dev_allocs.push_back(d);
+    HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = (float*)d;
+    return 0;
+}
+
+// Generic packer: rows n < N, k = tap*cinp + cmap(c).  `get(n, tap, c)` returns the (already scaled) weight.
+static int pack_conv(ccvpe_handle_s* h, PackedConv& pc, int N, int taps, int cin, int cinp, const std::vector<int>& cmap,
+                     const std::function<float(int, int, int)>& get, const std::vector<float>& bias, int KH, int KW) {
+    const int npad = round_up(N, conv_igemm_npad());
+    const int K = taps * cinp;
+    const int kpad = round_up(K, 32);
+    std::vector<float> w((size_t)npad * kpad, 0.f);
+    for (int n = 0; n < N; ++n)
+        for (int t = 0; t < taps; ++t)
+            for (int c = 0; c < cin; ++c) w[(size_t)n * kpad + t * cinp + cmap[c]] = get(n, t, c);
+    pc.N = N; pc.Kpad = kpad; pc.nchunks = K / 8; pc.cinp = cinp; pc.KH = KH; pc.KW = KW;
+    int rc = upload(h, w, &pc.w);
+    if (rc) return rc;
+    return upload(h, bias, &pc.bias);
+}
+static std::vector<int> identity_map(int n) { std::vector<int> m(n); for (int i = 0; i < n; ++i) m[i] = i; return m; }
+
+struct BnFold { std::vector<float> scale, shift; };
+static BnFold fold_bn(ccvpe_handle_s* h, const std::string& p) {
+    const auto& g = h->host[p + ".weight"]; const auto& b = h->host[p + ".bias"];
+    const auto& mu = h->host[p + ".running_mean"]; const auto& var = h->host[p + ".running_var"];
+    BnFold f; f.scale.resize(g.size()); f.shift.resize(g.size());
+    for (size_t i = 0; i < g.size(); ++i) {
+        float s = g[i] / std::sqrt(var[i] + BN_EPS);
+        f.scale[i] = s; f.shift[i] = b[i] - mu[i] * s;
+    }
+    return f;
+}
+
+static int pack_pointwise_bn(ccvpe_handle_s* h, PackedConv& pc, const std::string& wkey, const std::string& bnkey, int cout, int cin) {
+    const auto& w = h->host[wkey];
+    BnFold f = fold_bn(h, bnkey);
+    return pack_conv(h, pc, cout, 1, cin, cin, identity_map(cin),
+                     [&](int n, int, int c) { return w[(size_t)n * cin + c] * f.scale[n]; }, f.shift, 1, 1);
+}
+
+static int build_encoder(ccvpe_handle_s* h, EncoderW& e, const std::string& p) {
+    int rc;
+    {   // stem: [32][3][3][3] -> [27][32], k = (c*3+ky)*3+kx
+        const auto& w = h->host[p + "._conv_stem.weight"];
+        BnFold f = fold_bn(h, p + "._bn0");
+        std::vector<float> pk(27 * 32);
+        for (int o = 0; o < 32; ++o)
+            for (int k = 0; k < 27; ++k) pk[k * 32 + o] = w[o * 27 + k] * f.scale[o];
+        if ((rc = upload(h, pk, &e.stem_w))) return rc;
+        if ((rc = upload(h, f.shift, &e.stem_b))) return rc;
+    }
+    for (int i = 0; i < 16; ++i) {
+        const BlockSpec& b = B0[i];
+        BlockW& bw = e.blk[i];
+        std::string q = p + "._blocks." + std::to_string(i);
+        const int mid = b.cin * b.e;
+        if (b.e != 1 && (rc = pack_pointwise_bn(h, bw.expand, q + "._expand_conv.weight", q + "._bn0", mid, b.cin))) return rc;
+        {
+            const auto& w = h->host[q + "._depthwise_conv.weight"];
+            BnFold f = fold_bn(h, q + "._bn1");
+            const int kk = b.k * b.k;
+            std::vector<float> pk((size_t)kk * mid);
+            for (int c = 0; c < mid; ++c)
+                for (int t = 0; t < kk; ++t) pk[(size_t)t * mid + c] = w[(size_t)c * kk + t] * f.scale[c];
+            if ((rc = upload(h, pk, &bw.dw_w))) return rc;
+            if ((rc = upload(h, f.shift, &bw.dw_b))) return rc;
+        }
+        bw.sq = se_squeeze(b.cin);
+        if ((rc = upload(h, h->host[q + "._se_reduce.weight"], &bw.se_w1))) return rc;
+        if ((rc = upload(h, h->host[q + "._se_reduce.bias"], &bw.se_b1))) return rc;
+        if ((rc = upload(h, h->host[q + "._se_expand.weight"], &bw.se_w2))) return rc;
+        if ((rc = upload(h, h->host[q + "._se_expand.bias"], &bw.se_b2))) return rc;
+        if ((rc = pack_pointwise_bn(h, bw.project, q + "._project_conv.weight", q + "._bn2", b.cout, mid))) return rc;
+    }
+    return pack_pointwise_bn(h, e.head, p + "._conv_head.weight", p + "._bn1", 1280, 320);
+}
+
+static int score_pad(int nscore) { return round_up(nscore, 8); }
+
+static int build_decoder(ccvpe_handle_s* h, DecoderW& d, const DecLevel* lv, const std::string& sfx, int nscore_l6, bool every_level_scored) {
+    int rc;
+    for (int j = 0; j < 6; ++j) {
+        std::string n = std::to_string(6 - j);
+        {   // ConvTranspose2d weight [cin][cout][2][2] -> rows n = (dy*2+dx)*cout + o
+            const auto& w = h->host["deconv" + n + sfx + ".weight"];
+            const auto& b = h->host["deconv" + n + sfx + ".bias"];
+            const int cin = lv[j].din, cout = lv[j].dout;
+            int nscore = 0;
+            if (every_level_scored) nscore = 1;
+            else if (j == 0) nscore = nscore_l6;
+            const int spad = score_pad(nscore);
+            const int cinp = spad + (cin - nscore);
+            std::vector<int> cmap(cin);
+            for (int c = 0; c < cin; ++c) cmap[c] = c < nscore ? c : c - nscore + spad;
+            std::vector<float> bias(4 * cout);
+            for (int qd = 0; qd < 4; ++qd) for (int o = 0; o < cout; ++o) bias[qd * cout + o] = b[o];
+            if ((rc = pack_conv(h, d.deconv[j], 4 * cout, 1, cin, cinp, cmap,
+                                [&](int nn, int, int c) { int qd = nn / cout, o = nn % cout; return w[((size_t)c * cout + o) * 4 + qd]; },
+                                bias, 1, 1))) return rc;
+        }
+        {
+            const auto& w = h->host["conv" + n + sfx + ".0.weight"];
+            const int cin = lv[j].dout + lv[j].skip, cout = lv[j].mid;
+            if ((rc = pack_conv(h, d.conva[j], cout, 9, cin, cin, identity_map(cin),
+                                [&](int nn, int t, int c) { return w[((size_t)nn * cin + c) * 9 + t]; },
+                                h->host["conv" + n + sfx + ".0.bias"], 3, 3))) return rc;
+        }
+        const auto& w2 = h->host["conv" + n + sfx + ".2.weight"];
+        const auto& b2 = h->host["conv" + n + sfx + ".2.bias"];
+        if (j < 5) {
+            const int cin = lv[j].mid, cout = lv[j].out;
+            if ((rc = pack_conv(h, d.convb[j], cout, 9, cin, cin, identity_map(cin),
+                                [&](int nn, int t, int c) { return w2[((size_t)nn * cin + c) * 9 + t]; }, b2, 3, 3))) return rc;
+        } else {   // tail: [cout][16][3][3] -> [9][16][cout]
+            const int cout = lv[j].out;
+            std::vector<float> pk(9 * 16 * cout);
+            for (int o = 0; o < cout; ++o)
+                for (int c = 0; c < 16; ++c)
+                    for (int t = 0; t < 9; ++t) pk[(t * 16 + c) * cout + o] = w2[((size_t)o * 16 + c) * 9 + t];
+            if ((rc = upload(h, pk, &d.tail_w))) return rc;
+            for (int o = 0; o < cout; ++o) d.tail_b[o] = b2[o];
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// roll shifts (spec.py roll_shifts / full_roll_shifts; models.py:192-193, 489-491, 1094)
+// ------------------------------------------------------------------------------------------------
+static int window_offset(const VariantSpec& vs, int level, int L) {
+    const int C = vs.match_ch[level];
+    return vs.centre ? (int)((double)C / 2 - (double)L / 2) : 0;
+}
+static int mod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
+
+// ------------------------------------------------------------------------------------------------
+// plan construction
+// ------------------------------------------------------------------------------------------------
+static ConvParams conv_params(const PackedConv& pc, const float* in, int in_ld, int B, int H, int W, int OH, int OW,
+                              int stride, int pad_t, int pad_l, int act) {
+    ConvParams p{};
+    p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = pc.cinp; p.OH = OH; p.OW = OW;
+    p.KH = pc.KH; p.KW = pc.KW; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+    p.wpk = pc.w; p.Kpad = pc.Kpad; p.nchunks = pc.nchunks; p.bias = pc.bias; p.N = pc.N; p.act = act;
+    p.gate = nullptr; p.resid = nullptr; p.resid_ld = 0; p.ndst = 0; p.mode = MODE_CONV; p.deconv_cout = 0;
+    p.M = B * OH * OW;
+    return p;
+}
+
+struct EncOut { Tensor vol; Tensor tap[16]; };
+
+// dsts for tap blocks: concat tensors the project GEMM also writes into (level index 0..4 -> block TAP_BLOCK[i])
+struct TapDst { Tensor t[2]; int coff[2]; int n = 0; };
+
+static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool is_grd, int B, int H, int W, bool circular,
+                         const TapDst* tapdst, EncOut& out, const std::string& tag) {
+    int lo, hi;
+    static_pad(3, 2, lo, hi);
+    int ch = conv_out(H, 3, 2), cw = conv_out(W, 3, 2);
+    Tensor cur = pl.alloc(B, ch, cw, 32);
+    {
+        StemParams sp{};
+        sp.B = B; sp.H = H; sp.W = W; sp.OH = ch; sp.OW = cw; sp.pad_t = lo; sp.pad_l = lo; sp.circular = circular;
+        sp.w = ew.stem_w; sp.bias = ew.stem_b;
+        Tensor o = cur;
+        pl.add(tag + ".stem", {o}, [sp, o, is_grd](const Ctx& c) {
+            StemParams q = sp; q.in = is_grd ? c.grd : c.sat; q.out = c.ptr(o);
+            launch_stem(q, c.stream);
+        }, 2.0 * B * ch * cw * 32 * 27, 4.0 * B * (3.0 * H * W + 32.0 * ch * cw));
+    }
+    for (int i = 0; i < 16; ++i) {
+        const BlockSpec& b = B0[i];
+        const BlockW& bw = ew.blk[i];
+        const int mid = b.cin * b.e;
+        const std::string bn = tag + ".b" + std::to_string(i);
+        Tensor xin = cur;
+        Tensor e = xin;
+        if (b.e != 1) {
+            e = pl.alloc(B, ch, cw, mid);
+            const PackedConv* pc = &bw.expand;
+            const int hh = ch, ww = cw;
+            pl.add(bn + ".expand", {xin, e}, [=](const Ctx& c) {
+                ConvParams p = conv_params(*pc, c.ptr(xin), xin.C, B, hh, ww, hh, ww, 1, 0, 0, ACT_SWISH);
+                p.dst[0] = {c.ptr(e), mid, 0}; p.ndst = 1;
+                launch_conv_igemm(p, TILE_AUTO, c.stream);
+            }, 2.0 * B * ch * cw * b.cin * mid, 4.0 * B * ch * cw * (b.cin + mid));
+        }
+        static_pad(b.k, b.s, lo, hi);
+        const int oh = conv_out(ch, b.k, b.s), ow = conv_out(cw, b.k, b.s);
+        Tensor d = pl.alloc(B, oh, ow, mid);
+        const int S = depthwise_strip_lanes(B, oh, ow, mid);
+        Tensor pool = pl.alloc(B, 1, S, mid);
+        {
+            DwParams dp{};
+            dp.B = B; dp.H = ch; dp.W = cw; dp.C = mid; dp.OH = oh; dp.OW = ow; dp.k = b.k; dp.stride = b.s;
+            dp.pad_t = lo; dp.pad_l = lo; dp.circular = circular; dp.w = bw.dw_w; dp.bias = bw.dw_b; dp.S = S;
+            pl.add(bn + ".dw", {e, d, pool}, [=](const Ctx& c) {
+                DwParams q = dp; q.in = c.ptr(e); q.out = c.ptr(d); q.pool_partial = c.ptr(pool);
+                launch_depthwise(q, c.stream);
+            }, 2.0 * B * oh * ow * mid * b.k * b.k, 4.0 * B * mid * ((double)ch * cw + (double)oh * ow));
+        }
+        Tensor gate = pl.alloc(B, 1, 1, mid);
+        {
+            SeParams sp{};
+            sp.B = B; sp.S = S; sp.C = mid; sp.SQ = bw.sq; sp.inv_hw = 1.f / (float)(oh * ow);
+            sp.w1 = bw.se_w1; sp.b1 = bw.se_b1; sp.w2 = bw.se_w2; sp.b2 = bw.se_b2;
+            pl.add(bn + ".se", {pool, gate}, [=](const Ctx& c) {
+                SeParams q = sp; q.pool_partial = c.ptr(pool); q.gate = c.ptr(gate);
+                launch_se(q, c.stream);
+            }, 4.0 * B * mid * bw.sq, 4.0 * B * S * mid);
+        }
+        Tensor o = pl.alloc(B, oh, ow, b.cout);
+        {
+            const PackedConv* pc = &bw.project;
+            const bool skip = (b.s == 1 && b.cin == b.cout);
+            TapDst td;
+            if (tapdst) for (int t = 0; t < 5; ++t) if (TAP_BLOCK[t] == i) td = tapdst[t];
+            std::vector<Tensor> uses = {d, gate, o};
+            if (skip) uses.push_back(xin);
+            for (int t = 0; t < td.n; ++t) uses.push_back(td.t[t]);
+            pl.add(bn + ".project", uses, [=](const Ctx& c) {
+                ConvParams p = conv_params(*pc, c.ptr(d), mid, B, oh, ow, oh, ow, 1, 0, 0, ACT_NONE);
+                p.gate = c.ptr(gate);
+                if (skip) { p.resid = c.ptr(xin); p.resid_ld = xin.C; }
+                p.dst[0] = {c.ptr(o), o.C, 0}; p.ndst = 1;
+                for (int t = 0; t < td.n; ++t) p.dst[p.ndst++] = {c.ptr(td.t[t]), td.t[t].C, td.coff[t]};
+                launch_conv_igemm(p, TILE_AUTO, c.stream);
+            }, 2.0 * B * oh * ow * mid * b.cout, 4.0 * B * oh * ow * (mid + b.cout * (1 + td.n)));
+        }
+        out.tap[i] = o;
+        pl.taps[tag + "_block" + std::to_string(i)] = {o, 0, o.C};
+        cur = o; ch = oh; cw = ow;
+    }
+    Tensor vol = pl.alloc(B, ch, cw, 1280);
+    {
+        const PackedConv* pc = &ew.head;
+        Tensor x = cur;
+        const int hh = ch, ww = cw;
+        pl.add(tag + ".head", {x, vol}, [=](const Ctx& c) {
+            ConvParams p = conv_params(*pc, c.ptr(x), x.C, B, hh, ww, hh, ww, 1, 0, 0, ACT_SWISH);
+            p.dst[0] = {c.ptr(vol), 1280, 0}; p.ndst = 1;
+            launch_conv_igemm(p, TILE_AUTO, c.stream);
+        }, 2.0 * B * ch * cw * 320 * 1280, 4.0 * B * ch * cw * 1600);
+    }
+    out.vol = vol;
+    pl.taps[tag + "_volume"] = {vol, 0, 1280};
+}
+
+static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
+    const VariantSpec& vs = h->vs;
+    pl.B = B; pl.gh = gh; pl.gw = gw; pl.debug = h->debug;
+
+    // ---- geometry of the ground feature volume ----
+    int fh = conv_out(gh, 3, 2), fw = conv_out(gw, 3, 2);
+    for (int i = 0; i < 16; ++i) { fh = conv_out(fh, B0[i].k, B0[i].s); fw = conv_out(fw, B0[i].k, B0[i].s); }
+    if (fh != vs.feat_h)
+        return fail(CCVPE_EINVAL, "ground image %dx%d gives a %d-row feature volume, the descriptor heads expect %d rows", gh, gw, fh, vs.feat_h);
+    int L[6];
+    for (int k = 0; k < 6; ++k) {
+        L[k] = fw * vs.head_ch[k];
+        if (L[k] > vs.match_ch[k])
+            return fail(CCVPE_EINVAL, "descriptor length %d exceeds aerial channels %d at level %d", L[k], vs.match_ch[k], k + 1);
+    }
+
+    // ---- decoder concat buffers (allocated first: the aerial encoder's tap epilogues write into them) ----
+    const int D = vs.sat_desc;
+    const int rfull = vs.n_rolls;
+    const int rpad = score_pad(rfull);
+    Tensor loc_in[6], ori_in6;          // deconv inputs: [score pad 8 | C]
+    Tensor loc_cat[6], ori_cat[6];      // deconv out + skip (level index j = 0..5 <-> decoder level 6-j)
+    for (int j = 0; j < 6; ++j) {
+        const int hw_in = 8 << j;
+        loc_in[j] = pl.alloc(B, hw_in, hw_in, 8 + vs.match_ch[j]);
+        loc_cat[j] = pl.alloc(B, hw_in * 2, hw_in * 2, vs.loc[j].dout + vs.loc[j].skip);
+        ori_cat[j] = pl.alloc(B, hw_in * 2, hw_in * 2, vs.ori[j].dout + vs.ori[j].skip);
+    }
+    ori_in6 = pl.alloc(B, 8, 8, rpad + D);
+
+    // ---- encoders ----
+    EncOut genc, senc;
+    plan_encoder(h, pl, h->grd_enc, true, B, gh, gw, h->cfg.circular_padding != 0, nullptr, genc, "grd");
+    TapDst td[5];
+    for (int t = 0; t < 5; ++t) {
+        td[t].n = 2;
+        td[t].t[0] = loc_cat[t]; td[t].coff[0] = vs.loc[t].dout;
+        td[t].t[1] = ori_cat[t]; td[t].coff[1] = vs.ori[t].dout;
+    }
+    plan_encoder(h, pl, h->sat_enc, false, B, CCVPE_SAT_HW, CCVPE_SAT_HW, false, td, senc, "sat");
+
+    // ---- ground descriptors ----
+    int ntot = 0, ltot = 0, hoff[6], loff[6];
+    for (int k = 0; k < 6; ++k) { hoff[k] = ntot; ntot += vs.head_ch[k]; loff[k] = ltot; ltot += round_up(L[k], 4); }
+    Tensor ghead = pl.alloc(B, fh, fw, ntot);
+    Tensor desc = pl.alloc(B, 1, 1, ltot);
+    {
+        const PackedConv* pc = &h->grd_heads;
+        Tensor x = genc.vol;
+        pl.add("grd.heads", {x, ghead}, [=](const Ctx& c) {
+            ConvParams p = conv_params(*pc, c.ptr(x), 1280, B, fh, fw, fh, fw, 1, 0, 0, ACT_NONE);
+            p.dst[0] = {c.ptr(ghead), ntot, 0}; p.ndst = 1;
+            launch_conv_igemm(p, TILE_AUTO, c.stream);
+        }, 2.0 * B * fh * fw * 1280 * ntot, 4.0 * B * fh * fw * (1280 + ntot));
+        GrdDescParams gp{};
+        gp.B = B; gp.Hf = fh; gp.Wf = fw; gp.Ntot = ntot; gp.nlev = 6; gp.Ltot = ltot;
+        for (int k = 0; k < 6; ++k) { gp.c[k] = vs.head_ch[k]; gp.off[k] = hoff[k]; gp.wh[k] = h->grd_wh[k]; gp.b2[k] = h->grd_b2[k]; gp.loff[k] = loff[k]; }
+        pl.add("grd.desc", {ghead, desc}, [=](const Ctx& c) {
+            GrdDescParams q = gp; q.y = c.ptr(ghead); q.desc = c.ptr(desc);
+            launch_grd_desc(q, c.stream);
+        }, 2.0 * B * fh * fw * ntot, 4.0 * B * fh * fw * ntot);
+        for (int k = 0; k < 6; ++k) pl.taps["grd_desc" + std::to_string(k + 1)] = {desc, loff[k], L[k]};
+    }
+
+    // ---- aerial descriptor map: conv k2 s2 over the 1280x16x16 volume ----
+    Tensor dmap = pl.alloc(B, 8, 8, D);
+    {
+        const PackedConv* pc = &h->sat_desc;
+        Tensor x = senc.vol;
+        pl.add("sat.descmap", {x, dmap}, [=](const Ctx& c) {
+            ConvParams p = conv_params(*pc, c.ptr(x), 1280, B, 16, 16, 8, 8, 2, 0, 0, ACT_NONE);
+            p.dst[0] = {c.ptr(dmap), D, 0}; p.ndst = 1;
+            launch_conv_igemm(p, TILE_AUTO, c.stream);
+        }, 2.0 * B * 64 * 5120.0 * D, 4.0 * (B * 256 * 1280.0 + 5120.0 * D));
+        pl.taps["sat_descriptor_map"] = {dmap, 0, D};
+    }
+
+    // ---- decoders ----
+    auto plan_level = [&](const DecoderW& dw, const DecLevel* lv, int j, Tensor din, Tensor cat, const std::string& tag) -> Tensor {
+        const int hin = 8 << j, hout = hin * 2;
+        const DecLevel& l = lv[j];
+        {
+            const PackedConv* pc = &dw.deconv[j];
+            const int cout = l.dout;
+            pl.add(tag + ".deconv", {din, cat}, [=](const Ctx& c) {
+                ConvParams p = conv_params(*pc, c.ptr(din), din.C, B, hin, hin, hin, hin, 1, 0, 0, ACT_NONE);
+                p.mode = MODE_DECONV; p.deconv_cout = cout;
+                p.dst[0] = {c.ptr(cat), cat.C, 0}; p.ndst = 1;
+                launch_conv_igemm(p, TILE_AUTO, c.stream);
+            }, 2.0 * B * hin * hin * (double)l.din * 4 * l.dout, 4.0 * B * hin * hin * ((double)din.C + 4.0 * l.dout));
+        }
+        Tensor mid = pl.alloc(B, hout, hout, l.mid);
+        {
+            const PackedConv* pc = &dw.conva[j];
+            pl.add(tag + ".conv_a", {cat, mid}, [=](const Ctx& c) {
+                ConvParams p = conv_params(*pc, c.ptr(cat), cat.C, B, hout, hout, hout, hout, 1, 1, 1, ACT_RELU);
+                p.dst[0] = {c.ptr(mid), mid.C, 0}; p.ndst = 1;
+                launch_conv_igemm(p, TILE_AUTO, c.stream);
+            }, 2.0 * B * hout * hout * 9.0 * cat.C * l.mid, 4.0 * B * hout * hout * ((double)cat.C + l.mid));
+        }
+        if (j == 5) return mid;   // tail conv handled by the caller
+        Tensor o = pl.alloc(B, hout, hout, l.out);
+        {
+            const PackedConv* pc = &dw.convb[j];
+            pl.add(tag + ".conv_b", {mid, o}, [=](const Ctx& c) {
+                ConvParams p = conv_params(*pc, c.ptr(mid), mid.C, B, hout, hout, hout, hout, 1, 1, 1, ACT_NONE);
+                p.dst[0] = {c.ptr(o), o.C, 0}; p.ndst = 1;
+                launch_conv_igemm(p, TILE_AUTO, c.stream);
+            }, 2.0 * B * hout * hout * 9.0 * l.mid * l.out, 4.0 * B * hout * hout * ((double)l.mid + l.out));
+        }
+        return o;
+    };
+
+    Tensor x = dmap;
+    Tensor loc_mid;
+    for (int k = 0; k < 6; ++k) {   // matching level k+1 feeds decoder level 6-k
+        MatchParams mp{};
+        const int hw = (8 << k) * (8 << k);
+        const int C = vs.match_ch[k];
+        mp.x_ld = x.C; mp.B = B; mp.HW = hw; mp.C = C; mp.g_ld = ltot; mp.L = L[k];
+        const int off = window_offset(vs, k, L[k]);
+        const bool prior = h->cfg.variant == CCVPE_VARIANT_VIGOR_ORI_PRIOR;
+        const int n = prior ? (int)(h->cfg.ori_noise / 18.f) : 0;
+        if (k == 0 || !prior) {
+            mp.R = rfull;
+            for (int r = 0; r < rfull; ++r) mp.shift[r] = mod(off + r * vs.step[k], C);
+            mp.inmax = 0;
+            if (prior) { for (int i = -n; i <= n; ++i) mp.inmax |= 1u << mod(i, rfull); }
+            else mp.inmax = rfull >= 32 ? 0xffffffffu : ((1u << rfull) - 1u);
+        } else {
+            mp.R = 2 * n + 1;
+            for (int r = 0; r < mp.R; ++r) mp.shift[r] = mod(off + (r - n) * vs.step[k], C);
+            mp.inmax = (mp.R >= 32) ? 0xffffffffu : ((1u << mp.R) - 1u);
+        }
+        mp.rpad = rpad;
+        mp.P = match_pixels_per_block(hw, C);
+        mp.cat_max_ld = 8 + C;
+        mp.cat_all_ld = rpad + C;
+        Tensor xin = x, lin = loc_in[k];
+        const bool first = (k == 0);
+        const int goff = loff[k];
+        const int R = mp.R;
+        std::vector<Tensor> uses = {xin, desc, lin};
+        if (first) uses.push_back(ori_in6);
+        pl.add("match" + std::to_string(k + 1), uses, [=](const Ctx& c) {
+            MatchParams q = mp;
+            q.x = c.ptr(xin); q.g = c.ptr(desc) + goff;
+            q.ms = c.out.matching_score[k];
+            q.cat_max = c.ptr(lin);
+            q.cat_all = first ? c.ptr(ori_in6) : nullptr;
+            launch_match(q, c.stream);
+        }, 4.0 * B * hw * (double)R * L[k], 4.0 * B * hw * (2.0 * C + R + 8));
+        pl.taps["loc_in" + std::to_string(6 - k)] = {lin, 0, lin.C};
+        Tensor o = plan_level(h->loc, vs.loc, k, lin, loc_cat[k], "loc" + std::to_string(6 - k));
+        if (k < 5) { pl.taps["loc_level" + std::to_string(6 - k)] = {o, 0, o.C}; x = o; }
+        else loc_mid = o;
+    }
+    {
+        Tensor m = loc_mid;
+        const float* tw = h->loc.tail_w;
+        const float tb = h->loc.tail_b[0];
+        pl.add("loc1.tail", {m}, [=](const Ctx& c) {
+            TailConvParams p{};
+            p.in = c.ptr(m); p.B = B; p.H = CCVPE_OUT_HW; p.W = CCVPE_OUT_HW; p.w = tw; p.bias[0] = tb; p.cout = 1;
+            p.normalize = 0; p.out = c.out.logits_flattened; p.raw = nullptr;
+            launch_tail_conv(p, c.stream);
+        }, 2.0 * B * 262144.0 * 144, 4.0 * B * 262144.0 * 17);
+        Tensor part = pl.alloc(B, 1, 64, 2);
+        pl.add("softmax", {part}, [=](const Ctx& c) {
+            SoftmaxParams p{};
+            p.logits = c.out.logits_flattened; p.B = B; p.n = CCVPE_OUT_HW * CCVPE_OUT_HW; p.partial = c.ptr(part); p.chunks = 64;
+            p.out = c.out.heatmap;
+            launch_softmax(p, c.stream);
+        }, 0, 4.0 * B * 262144.0 * 3);
+    }
+    // orientation decoder
+    {
+        Tensor xo = ori_in6;
+        Tensor ori_mid;
+        for (int j = 0; j < 6; ++j) {
+            Tensor o = plan_level(h->ori, vs.ori, j, xo, ori_cat[j], "ori" + std::to_string(6 - j));
+            if (j < 5) { pl.taps["ori_level" + std::to_string(6 - j)] = {o, 0, o.C}; xo = o; }
+            else ori_mid = o;
+        }
+        Tensor raw;
+        if (h->debug) { raw = pl.alloc(B, 2, CCVPE_OUT_HW, CCVPE_OUT_HW); pl.taps["ori_level1_nchw"] = {raw, 0, -1}; }
+        Tensor m = ori_mid;
+        const float* tw = h->ori.tail_w;
+        const float tb0 = h->ori.tail_b[0], tb1 = h->ori.tail_b[1];
+        const bool dbg = h->debug;
+        std::vector<Tensor> uses = {m};
+        if (dbg) uses.push_back(raw);
+        pl.add("ori1.tail", uses, [=](const Ctx& c) {
+            TailConvParams p{};
+            p.in = c.ptr(m); p.B = B; p.H = CCVPE_OUT_HW; p.W = CCVPE_OUT_HW; p.w = tw; p.bias[0] = tb0; p.bias[1] = tb1; p.cout = 2;
+            p.normalize = 1; p.out = c.out.ori; p.raw = dbg ? c.ptr(raw) : nullptr;
+            launch_tail_conv(p, c.stream);
+        }, 2.0 * B * 262144.0 * 288, 4.0 * B * 262144.0 * 18);
+    }
+    pl.assign();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* ccvpe_last_error(void) { return g_err.c_str(); }
+const char* ccvpe_version(void) { return "ccvpe-hip 0.1 (gfx950, fp32 MFMA)"; }
+
+int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
+    if (!cfg || !out) return fail(CCVPE_EINVAL, "null argument");
+    if (cfg->variant < 0 || cfg->variant > 3) return fail(CCVPE_EINVAL, "unknown variant %d", cfg->variant);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(CCVPE_EHIP, "no HIP device visible: libccvpe_hip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(CCVPE_EINVAL, "device %d out of range (%d visible)", cfg->device, ndev);
+    HIPCHK(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(CCVPE_EHIP, "device %d is %s; this library carries gfx950 code objects only", cfg->device, prop.gcnArchName);
+    auto* h = new ccvpe_handle_s();
+    h->cfg = *cfg;
+    if (h->cfg.micro_batch <= 0) h->cfg.micro_batch = 32;
+    h->vs = make_variant(cfg->variant);
+    const int n = (int)(cfg->ori_noise / 18.f);
+    for (int k = 0; k < 6; ++k)
+        h->rolls[k] = (cfg->variant == CCVPE_VARIANT_VIGOR_ORI_PRIOR && k > 0) ? 2 * n + 1 : h->vs.n_rolls;
+    if (cfg->variant == CCVPE_VARIANT_VIGOR_ORI_PRIOR && (n < 0 || 2 * n + 1 > 32)) {
+        delete h;
+        return fail(CCVPE_EINVAL, "ori_noise %.1f out of range", cfg->ori_noise);
+    }
+    build_expect(h);
+    *out = h;
+    return 0;
+}
+
+int ccvpe_destroy(ccvpe_handle h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->cfg.device);
+    for (void* p : h->dev_allocs) (void)hipFree(p);
+    if (h->arena) (void)hipFree(h->arena);
+    delete h;
+    return 0;
+}
+
+int ccvpe_skip_weight(ccvpe_handle h, const char* key) {
+    if (!h || !key) return fail(CCVPE_EINVAL, "null argument");
+    if (!h->expect.count(key)) return fail(CCVPE_EKEY, "unexpected state_dict key '%s'", key);
+    h->skipped.insert(key);
+    return 0;
+}
+
+int ccvpe_set_weight(ccvpe_handle h, const char* key, const float* data, const int64_t* shape, int32_t ndim) {
+    if (!h || !key || !data) return fail(CCVPE_EINVAL, "null argument");
+    auto it = h->expect.find(key);
+    if (it == h->expect.end()) return fail(CCVPE_EKEY, "unexpected state_dict key '%s'", key);
+    const auto& es = it->second;
+    bool ok = (int)es.size() == ndim;
+    size_t n = 1;
+    for (int i = 0; ok && i < ndim; ++i) { ok = es[i] == shape[i]; n *= (size_t)shape[i]; }
+    if (!ok) return fail(CCVPE_EINVAL, "shape mismatch for '%s'", key);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    std::vector<float> v(n);
+    HIPCHK(hipMemcpy(v.data(), data, n * sizeof(float), hipMemcpyDefault));
+    h->host[key] = std::move(v);
+    h->finalized = false;
+    return 0;
+}
+
+int ccvpe_finalize_weights(ccvpe_handle h) {
+    if (!h) return fail(CCVPE_EINVAL, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    for (auto& kv : h->expect) {
+        const std::string& k = kv.first;
+        const bool optional = k.find("num_batches_tracked") != std::string::npos || k.find("._fc.") != std::string::npos;
+        if (!h->host.count(k) && !(optional || h->skipped.count(k)))
+            return fail(CCVPE_EKEY, "missing state_dict key '%s'", k.c_str());
+        if (!h->host.count(k) && !optional) return fail(CCVPE_EKEY, "key '%s' was skipped but is required", k.c_str());
+    }
+    // drop previous device copies (re-finalize after a new load_state_dict)
+    for (void* p : h->dev_allocs) (void)hipFree(p);
+    h->dev_allocs.clear();
+    h->plans.clear();
+    int rc;
+    if ((rc = build_encoder(h, h->grd_enc, "grd_efficientnet"))) return rc;
+    if ((rc = build_encoder(h, h->sat_enc, "sat_efficientnet"))) return rc;
+    {   // ground descriptor heads: one 1280 -> sum(c_k) pointwise GEMM, then per-level row weights
+        int ntot = 0;
+        for (int k = 0; k < 6; ++k) ntot += h->vs.head_ch[k];
+        std::vector<float> bias(ntot);
+        std::vector<const std::vector<float>*> ws(6);
+        std::vector<int> lvl(ntot), loc(ntot);
+        int o = 0;
+        for (int k = 0; k < 6; ++k) {
+            std::string p = "grd_feature_to_descriptor" + std::to_string(k + 1);
+            ws[k] = &h->host[p + ".0.weight"];
+            const auto& b = h->host[p + ".0.bias"];
+            for (int c = 0; c < h->vs.head_ch[k]; ++c, ++o) { bias[o] = b[c]; lvl[o] = k; loc[o] = c; }
+            if ((rc = upload(h, h->host[p + ".2.weight"], &h->grd_wh[k]))) return rc;
+            h->grd_b2[k] = h->host[p + ".2.bias"][0];
+        }
+        if ((rc = pack_conv(h, h->grd_heads, ntot, 1, 1280, 1280, identity_map(1280),
+                            [&](int n, int, int c) { return (*ws[lvl[n]])[(size_t)loc[n] * 1280 + c]; }, bias, 1, 1))) return rc;
+    }
+    {   // Linear(5120, D) == conv k2 s2: flat index ch*4 + dy*2 + dx (models.py:400-402, 471-482)
+        const auto& w = h->host["sat_feature_to_descriptors.1.weight"];
+        const int D = h->vs.sat_desc;
+        if ((rc = pack_conv(h, h->sat_desc, D, 4, 1280, 1280, identity_map(1280),
+                            [&](int n, int t, int c) { return w[(size_t)n * 5120 + c * 4 + t]; },
+                            h->host["sat_feature_to_descriptors.1.bias"], 2, 2))) return rc;
+    }
+    if ((rc = build_decoder(h, h->loc, h->vs.loc, "", 1, true))) return rc;
+    if ((rc = build_decoder(h, h->ori, h->vs.ori, "_ori", h->vs.n_rolls, false))) return rc;
+    h->host.clear();
+    h->finalized = true;
+    return 0;
+}
+
+int ccvpe_output_channels(ccvpe_handle h, int32_t level) {
+    if (!h || level < 0 || level > 5) return fail(CCVPE_EINVAL, "bad level");
+    return h->rolls[level];
+}
+
+static int get_plan(ccvpe_handle h, int B, int gh, int gw, Plan** out) {
+    for (auto& p : h->plans)
+        if (p->B == B && p->gh == gh && p->gw == gw && p->debug == h->debug) { *out = p.get(); return 0; }
+    auto pl = std::make_unique<Plan>();
+    int rc = build_plan(h, *pl, B, gh, gw);
+    if (rc) return rc;
+    if (pl->total > h->arena_floats) {
+        // growing the arena is the only synchronising step; it happens on the first call per shape
+        HIPCHK(hipDeviceSynchronize());
+        if (h->arena) HIPCHK(hipFree(h->arena));
+        h->arena = nullptr;
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, pl->total * sizeof(float));
+        if (e != hipSuccess) { h->arena_floats = 0; return fail(CCVPE_ENOMEM, "workspace of %zu bytes: %s", pl->total * sizeof(float), hipGetErrorString(e)); }
+        h->arena = (float*)d;
+        h->arena_floats = pl->total;
+    }
+    *out = pl.get();
+    h->plans.push_back(std::move(pl));
+    return 0;
+}
+
+size_t ccvpe_workspace_bytes(ccvpe_handle h, int32_t batch, int32_t grd_h, int32_t grd_w) {
+    if (!h || !h->finalized || batch <= 0) { fail(CCVPE_ESTATE, "handle not ready"); return 0; }
+    Plan pl;
+    const int mb = std::min(batch, h->cfg.micro_batch);
+    if (build_plan(h, pl, mb, grd_h, grd_w)) return 0;
+    return pl.total * sizeof(float);
+}
+
+static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const float* sat, int batch,
+                       const ccvpe_outputs* out, hipStream_t stream, bool profile) {
+    if (!h || !grd || !sat || !out) return fail(CCVPE_EINVAL, "null argument");
+    if (!h->finalized) return fail(CCVPE_ESTATE, "ccvpe_finalize_weights has not been called");
+    if (batch <= 0) return fail(CCVPE_EINVAL, "batch must be positive");
+    if (!out->logits_flattened || !out->heatmap || !out->ori) return fail(CCVPE_EINVAL, "null output buffer");
+    for (int k = 0; k < 6; ++k) if (!out->matching_score[k]) return fail(CCVPE_EINVAL, "null matching_score[%d]", k);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (profile) h->prof.clear();
+    const int mbmax = h->cfg.micro_batch;
+    // make sure every plan (and the largest arena) exists before the first launch
+    for (int done = 0; done < batch;) {
+        const int mb = std::min(mbmax, batch - done);
+        Plan* pl; int rc = get_plan(h, mb, gh, gw, &pl);
+        if (rc) return rc;
+        done += mb;
+    }
+    const size_t npx = (size_t)CCVPE_OUT_HW * CCVPE_OUT_HW;
+    for (int done = 0; done < batch;) {
+        const int mb = std::min(mbmax, batch - done);
+        Plan* pl; int rc = get_plan(h, mb, gh, gw, &pl);
+        if (rc) return rc;
+        Ctx c;
+        c.arena = h->arena; c.off = &pl->off; c.stream = stream;
+        c.grd = grd + (size_t)done * 3 * gh * gw;
+        c.sat = sat + (size_t)done * 3 * CCVPE_SAT_HW * CCVPE_SAT_HW;
+        c.out.logits_flattened = out->logits_flattened + done * npx;
+        c.out.heatmap = out->heatmap + done * npx;
+        c.out.ori = out->ori + done * 2 * npx;
+        for (int k = 0; k < 6; ++k) {
+            const size_t hw = (size_t)(8 << k) * (8 << k);
+            c.out.matching_score[k] = out->matching_score[k] + (size_t)done * h->rolls[k] * hw;
+        }
+        if (!profile) {
+            for (auto& op : pl->ops) op.fn(c);
+        } else {
+            hipEvent_t e0, e1;
+            HIPCHK(hipEventCreate(&e0));
+            HIPCHK(hipEventCreate(&e1));
+            for (auto& op : pl->ops) {
+                HIPCHK(hipEventRecord(e0, stream));
+                op.fn(c);
+                HIPCHK(hipEventRecord(e1, stream));
+                HIPCHK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+                h->prof.push_back({op.name, ms, op.flops, op.bytes});
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        done += mb;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CCVPE_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int ccvpe_forward(ccvpe_handle h, const float* grd, int32_t grd_h, int32_t grd_w, const float* sat, int32_t batch,
+                  const ccvpe_outputs* out, void* stream) {
+    return run_forward(h, grd, grd_h, grd_w, sat, batch, out, (hipStream_t)stream, false);
+}
+
+int ccvpe_profile_forward(ccvpe_handle h, const float* grd, int32_t grd_h, int32_t grd_w, const float* sat, int32_t batch,
+                          const ccvpe_outputs* out, void* stream) {
+    int rc = run_forward(h, grd, grd_h, grd_w, sat, batch, out, (hipStream_t)stream, true);
+    if (rc) return rc;
+    return (int)h->prof.size();
+}
+
+int ccvpe_profile_row(ccvpe_handle h, int32_t i, char* name_buf, size_t name_cap, float* ms, double* flops, double* bytes) {
+    if (!h || i < 0 || i >= (int)h->prof.size()) return fail(CCVPE_EINVAL, "row out of range");
+    const auto& r = h->prof[i];
+    if (name_buf && name_cap) { std::strncpy(name_buf, r.name.c_str(), name_cap - 1); name_buf[name_cap - 1] = 0; }
+    if (ms) *ms = r.ms;
+    if (flops) *flops = r.flops;
+    if (bytes) *bytes = r.bytes;
+    return 0;
+}
+
+int ccvpe_postprocess(ccvpe_handle h, const float* heatmap, const float* ori, int32_t batch, ccvpe_pose* poses, void* stream) {
+    if (!h || !heatmap || !ori || !poses || batch <= 0) return fail(CCVPE_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    static_assert(sizeof(ccvpe_pose) == sizeof(PoseOut), "pose layout");
+    launch_postprocess(heatmap, ori, batch, CCVPE_OUT_HW * CCVPE_OUT_HW, reinterpret_cast<PoseOut*>(poses), (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CCVPE_EHIP, "postprocess launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int ccvpe_set_debug(ccvpe_handle h, int32_t enable) {
+    if (!h) return fail(CCVPE_EINVAL, "null handle");
+    h->debug = enable != 0;
+    return 0;
+}
+
+int ccvpe_read_tap(ccvpe_handle h, const char* name, float* host_dst, size_t capacity, size_t* n_out, int32_t shape_out[4]) {
+    if (!h || !name || !host_dst) return fail(CCVPE_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    Plan* pl = nullptr;
+    for (auto it = h->plans.rbegin(); it != h->plans.rend(); ++it)
+        if ((*it)->debug) { pl = it->get(); break; }
+    if (!pl) return fail(CCVPE_ESTATE, "no debug plan: call ccvpe_set_debug(h, 1) before forward");
+    auto it = pl->taps.find(name);
+    if (it == pl->taps.end()) return fail(CCVPE_EKEY, "unknown tap '%s'", name);
+    const TapInfo& ti = it->second;
+    const Tensor& t = ti.t;
+    float* base = h->arena + pl->off[t.id];
+    HIPCHK(hipDeviceSynchronize());
+    if (ti.C < 0) {   // already NCHW
+        const size_t n = (size_t)t.B * t.H * t.W * t.C;
+        if (n > capacity) return fail(CCVPE_EINVAL, "tap needs %zu floats", n);
+        HIPCHK(hipMemcpy(host_dst, base, n * sizeof(float), hipMemcpyDeviceToHost));
+        if (n_out) *n_out = n;
+        if (shape_out) { shape_out[0] = t.B; shape_out[1] = t.H; shape_out[2] = t.W; shape_out[3] = t.C; }
+        return 0;
+    }
+    const int hw = t.H * t.W;
+    const size_t n = (size_t)t.B * ti.C * hw;
+    if (n > capacity) return fail(CCVPE_EINVAL, "tap needs %zu floats", n);
+    float* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, n * sizeof(float)));
+    launch_nhwc_to_nchw(base, t.C, ti.coff, ti.C, t.B, hw, tmp, nullptr);
+    hipError_t e = hipMemcpy(host_dst, tmp, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(CCVPE_EHIP, "tap copy failed: %s", hipGetErrorString(e));
+    if (n_out) *n_out = n;
+    if (shape_out) { shape_out[0] = t.B; shape_out[1] = ti.C; shape_out[2] = t.H; shape_out[3] = t.W; }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+// Internal kernel interface of libccvpe_hip.so (gfx950 only).  All activations are fp32 NHWC.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ccvpe {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SWISH = 2 };
+
+// A destination view of an NHWC tensor: element (pixel p, channel c) lives at ptr[p*ld + coff + c].
+struct Dst {
+    float* ptr;
+    int ld;
+    int coff;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//   out[m, n] = act( sum_k A[m, k] * Wp[n, k] + bias[n] ) (+ resid[m, n])
+// m = output pixel (b, oy, ox) for MODE_CONV, input pixel for MODE_DECONV (k2 s2 transposed conv,
+// n = (dy*2+dx)*cout + o, pixel-shuffled on store).  k = (ky*KW + kx)*Cin + c, Cin % 8 == 0.
+// ---------------------------------------------------------------------------------------------
+enum { MODE_CONV = 0, MODE_DECONV = 1 };
+
+struct ConvParams {
+    const float* in;
+    int in_ld;                 // floats per input pixel (>= Cin)
+    int B, H, W, Cin;          // input geometry
+    int OH, OW;                // GEMM-row geometry (conv: output map; deconv: == H, W)
+    int KH, KW, stride, pad_t, pad_l;
+    const float* wpk;          // [Npad][Kpad], k contiguous
+    int Kpad;                  // multiple of 32
+    int nchunks;               // KH*KW*Cin/8 valid 8-channel chunks
+    const float* bias;         // [N]
+    int N;
+    int act;
+    const float* gate;         // optional [B][Cin] multiplier on A (squeeze-excite), 1x1 only
+    const float* resid;        // optional residual [M][resid_ld]
+    int resid_ld;
+    Dst dst[3];
+    int ndst;
+    int mode;
+    int deconv_cout;
+    int M;                     // B*OH*OW
+};
+
+// tile = 0 picks automatically from (M, N); otherwise one of the TILE_* ids.
+enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_128x32 = 4 };
+void launch_conv_igemm(const ConvParams& p, int tile, hipStream_t s);
+int conv_igemm_npad();       // row padding of packed weights (multiple every tile divides)
+
+// ---------------------------------------------------------------------------------------------
+// Encoder pieces
+// ---------------------------------------------------------------------------------------------
+struct StemParams {
+    const float* in;           // NCHW [B,3,H,W]
+    int B, H, W, OH, OW;
+    int pad_t, pad_l;
+    int circular;
+    const float* w;            // [27][32]  k = (c*3+ky)*3+kx, BN folded
+    const float* bias;         // [32]
+    float* out;                // NHWC [B,OH,OW,32]
+};
+void launch_stem(const StemParams& p, hipStream_t s);
+
+struct DwParams {
+    const float* in;           // NHWC [B,H,W,C]
+    int B, H, W, C, OH, OW;
+    int k, stride, pad_t, pad_l, circular;
+    const float* w;            // [k*k][C], BN folded
+    const float* bias;         // [C]
+    float* out;                // NHWC [B,OH,OW,C], swish applied
+    float* pool_partial;       // [B][S][C] partial sums of `out` for squeeze-excite
+    int S;                     // strip lanes per sample
+};
+void launch_depthwise(const DwParams& p, hipStream_t s);
+int depthwise_strip_lanes(int B, int OH, int OW, int C);
+
+struct SeParams {
+    const float* pool_partial; // [B][S][C]
+    int B, S, C, SQ;
+    float inv_hw;
+    const float* w1;           // [SQ][C]
+    const float* b1;           // [SQ]
+    const float* w2;           // [C][SQ]
+    const float* b2;           // [C]
+    float* gate;               // [B][C] sigmoid(...)
+};
+void launch_se(const SeParams& p, hipStream_t s);
+
+// ground descriptor: d_k[b][w*c_k + ch] = b2_k + sum_h wh_k[h] * Y[b,h,w,off_k+ch]
+struct GrdDescParams {
+    const float* y;            // NHWC [B,Hf,Wf,Ntot] (1x1 conv output incl. bias)
+    int B, Hf, Wf, Ntot;
+    int nlev;
+    int c[6], off[6];          // per level head width and channel offset in y
+    const float* wh[6];        // [Hf]
+    float b2[6];
+    float* desc;               // [B][Ltot] levels back to back
+    int loff[6];               // element offset of level k inside a sample's row
+    int Ltot;
+};
+void launch_grd_desc(const GrdDescParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Rolling match + L2 normalise + concat
+// ---------------------------------------------------------------------------------------------
+struct MatchParams {
+    const float* x;            // NHWC [B,HW,C] (ld = x_ld)
+    int x_ld;
+    int B, HW, C;
+    const float* g;            // [B][g_ld] descriptor, first L used
+    int g_ld, L;
+    int R;
+    int shift[32];             // window_r[c] = x[(c + shift[r]) mod C]
+    uint32_t inmax;            // rolls that take part in the max
+    float* ms;                 // NCHW [B,R,HW] or null
+    // loc concat buffer: ch0 = max, ch1..7 = 0, ch 8.. = normalised x
+    float* cat_max;  int cat_max_ld;
+    // ori concat buffer: ch0..R-1 = scores, zero pad to rpad, then normalised x
+    float* cat_all;  int cat_all_ld;  int rpad;
+    int P;                     // pixels per block (power of two, divides HW)
+};
+void launch_match(const MatchParams& p, hipStream_t s);
+int match_pixels_per_block(int HW, int C);
+
+// ---------------------------------------------------------------------------------------------
+// Tail: 16 -> {1,2} 3x3 conv to NCHW (+ unit-normalise for ori), softmax, post-processing
+// ---------------------------------------------------------------------------------------------
+struct TailConvParams {
+    const float* in;           // NHWC [B,H,W,16]
+    int B, H, W;
+    const float* w;            // [9][16][cout]
+    float bias[2];
+    int cout;                  // 1 or 2
+    int normalize;             // L2 normalise over the cout channels (F.normalize, eps 1e-12)
+    float* out;                // NCHW [B,cout,H,W]
+    float* raw;                // optional NCHW un-normalised copy (debug tap) or null
+};
+void launch_tail_conv(const TailConvParams& p, hipStream_t s);
+
+struct SoftmaxParams {
+    const float* logits;       // [B][n]
+    int B, n;
+    float* partial;            // [B][chunks][2]
+    int chunks;
+    float* out;                // [B][n]
+};
+void launch_softmax(const SoftmaxParams& p, hipStream_t s);
+
+struct PoseOut { int32_t index; float prob, cos_v, sin_v, angle_deg; };
+void launch_postprocess(const float* heat, const float* ori, int B, int n, PoseOut* out, hipStream_t s);
+
+void launch_nhwc_to_nchw(const float* in, int in_ld, int coff, int C, int B, int HW, float* out, hipStream_t s);
+
+}  // namespace ccvpe

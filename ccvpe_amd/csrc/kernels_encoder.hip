@@ -1,0 +1,230 @@
+// HBM-bound encoder kernels: stem conv, depthwise conv (+BN+swish+SE pooling), squeeze-excite MLP,
+// ground-descriptor row reduction.  fp32, NHWC, float4 (16 B/lane) accesses, BN pre-folded.
+//
+// Reference call sites: efficientnet_pytorch/model.py:289 (stem), :108-110 (depthwise + bn1 + swish),
+// :113-118 (squeeze-excite), utils.py:254-358 (static zero / horizontal-circular padding),
+// models.py:355-395 (ground descriptor heads: permute + Conv2d(H_f,1,1) + flatten).
+#include "kernels.h"
+
+namespace ccvpe {
+
+__device__ __forceinline__ float swishf(float v) { return v / (1.f + __expf(-v)); }
+
+// ------------------------------------------------------------------------------------------------
+// Stem: 3x3 stride 2, 3 -> 32 channels, NCHW input -> NHWC output, BN + swish.
+// thread = (output pixel, group of 4 output channels); 8 consecutive lanes share a pixel so the
+// 27 input taps are broadcast loads and the store is a fully coalesced 16 B/lane stream.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
+    __shared__ float ws[27 * 32];
+    __shared__ float bs[32];
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = p.w[i];
+    if (threadIdx.x < 32) bs[threadIdx.x] = p.bias[threadIdx.x];
+    __syncthreads();
+    const long long total = (long long)p.B * p.OH * p.OW * 8;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+        const int cg = (int)(it & 7);
+        long long pix = it >> 3;
+        const int ox = (int)(pix % p.OW);
+        long long t = pix / p.OW;
+        const int oy = (int)(t % p.OH);
+        const int b = (int)(t / p.OH);
+        float4 acc = *reinterpret_cast<const float4*>(bs + cg * 4);
+        const float* inb = p.in + (size_t)b * 3 * p.H * p.W;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - p.pad_t + ky;
+            if ((unsigned)iy >= (unsigned)p.H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                int ix = ox * 2 - p.pad_l + kx;
+                if (p.circular) {
+                    if (ix < 0) ix += p.W;
+                    if (ix >= p.W) ix -= p.W;
+                } else if ((unsigned)ix >= (unsigned)p.W) {
+                    continue;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float v = inb[((size_t)c * p.H + iy) * p.W + ix];
+                    const float4 w = *reinterpret_cast<const float4*>(ws + ((c * 3 + ky) * 3 + kx) * 32 + cg * 4);
+                    acc.x = fmaf(v, w.x, acc.x);
+                    acc.y = fmaf(v, w.y, acc.y);
+                    acc.z = fmaf(v, w.z, acc.z);
+                    acc.w = fmaf(v, w.w, acc.w);
+                }
+            }
+        }
+        acc.x = swishf(acc.x); acc.y = swishf(acc.y); acc.z = swishf(acc.z); acc.w = swishf(acc.w);
+        *reinterpret_cast<float4*>(p.out + pix * 32 + cg * 4) = acc;
+    }
+}
+
+void launch_stem(const StemParams& p, hipStream_t s) {
+    long long total = (long long)p.B * p.OH * p.OW * 8;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(stem_kernel, dim3(blocks), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise k x k (k = 3 | 5), stride 1 | 2, static zero / horizontal-circular padding, BN + swish,
+// plus per-(sample, strip-lane, channel) partial sums for the squeeze-excite average pool.
+// thread = (4 channels, strip of TX output pixels along x); the k + (TX-1)*stride input columns of a
+// strip are loaded once per filter row and reused across the TX outputs.  A thread walks strips
+// lane, lane+S, ... of one sample, so its pooled partial sum is private and deterministic.
+// ------------------------------------------------------------------------------------------------
+template <int K, int STRIDE, int TX>
+__global__ __launch_bounds__(256) void depthwise_kernel(const DwParams p) {
+    constexpr int NCOL = K + (TX - 1) * STRIDE;
+    const int cg_n = p.C >> 2;
+    const int sx_n = (p.OW + TX - 1) / TX;
+    const int nstrips = p.OH * sx_n;
+    const long long total = (long long)p.B * p.S * cg_n;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+        const int cg = (int)(it % cg_n);
+        long long t = it / cg_n;
+        const int lane_s = (int)(t % p.S);
+        const int b = (int)(t / p.S);
+        const int c0 = cg * 4;
+        const float4 bias = *reinterpret_cast<const float4*>(p.bias + c0);
+        float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* inb = p.in + (size_t)b * p.H * p.W * p.C + c0;
+        float* outb = p.out + (size_t)b * p.OH * p.OW * p.C + c0;
+        for (int strip = lane_s; strip < nstrips; strip += p.S) {
+            const int oy = strip / sx_n;
+            const int ox0 = (strip - oy * sx_n) * TX;
+            float4 acc[TX];
+#pragma unroll
+            for (int i = 0; i < TX; ++i) acc[i] = bias;
+            const int ix0 = ox0 * STRIDE - p.pad_l;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const int iy = oy * STRIDE - p.pad_t + ky;
+                if ((unsigned)iy >= (unsigned)p.H) continue;
+                const float* row = inb + (size_t)iy * p.W * p.C;
+                float4 col[NCOL];
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j) {
+                    int ix = ix0 + j;
+                    bool ok = true;
+                    if (p.circular) {
+                        if (ix < 0) ix += p.W;
+                        else if (ix >= p.W) ix -= p.W;
+                        ok = (unsigned)ix < (unsigned)p.W;   // strips past the right edge
+                    } else {
+                        ok = (unsigned)ix < (unsigned)p.W;
+                    }
+                    col[j] = ok ? *reinterpret_cast<const float4*>(row + (size_t)ix * p.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float4 w = *reinterpret_cast<const float4*>(p.w + (ky * K + kx) * p.C + c0);
+#pragma unroll
+                    for (int i = 0; i < TX; ++i) {
+                        const float4 v = col[i * STRIDE + kx];
+                        acc[i].x = fmaf(v.x, w.x, acc[i].x);
+                        acc[i].y = fmaf(v.y, w.y, acc[i].y);
+                        acc[i].z = fmaf(v.z, w.z, acc[i].z);
+                        acc[i].w = fmaf(v.w, w.w, acc[i].w);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TX; ++i) {
+                if (ox0 + i < p.OW) {
+                    float4 o;
+                    o.x = swishf(acc[i].x); o.y = swishf(acc[i].y); o.z = swishf(acc[i].z); o.w = swishf(acc[i].w);
+                    pool.x += o.x; pool.y += o.y; pool.z += o.z; pool.w += o.w;
+                    *reinterpret_cast<float4*>(outb + ((size_t)oy * p.OW + ox0 + i) * p.C) = o;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(p.pool_partial + ((size_t)b * p.S + lane_s) * p.C + c0) = pool;
+    }
+}
+
+static constexpr int DW_TX = 4;
+
+int depthwise_strip_lanes(int B, int OH, int OW, int C) {
+    const int sx_n = (OW + DW_TX - 1) / DW_TX;
+    const int nstrips = OH * sx_n;
+    const long long target = 256LL * 2048;   // ~8 waves per SIMD over the chip
+    long long s = target / ((long long)B * (C / 4));
+    if (s < 1) s = 1;
+    if (s > nstrips) s = nstrips;
+    return (int)s;
+}
+
+void launch_depthwise(const DwParams& p, hipStream_t s) {
+    long long total = (long long)p.B * p.S * (p.C / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (p.k == 3 && p.stride == 1) hipLaunchKernelGGL((depthwise_kernel<3, 1, DW_TX>), dim3(blocks), dim3(256), 0, s, p);
+    else if (p.k == 3 && p.stride == 2) hipLaunchKernelGGL((depthwise_kernel<3, 2, DW_TX>), dim3(blocks), dim3(256), 0, s, p);
+    else if (p.k == 5 && p.stride == 1) hipLaunchKernelGGL((depthwise_kernel<5, 1, DW_TX>), dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((depthwise_kernel<5, 2, DW_TX>), dim3(blocks), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Squeeze-excite: pooled mean -> 1x1 (C->SQ) + swish -> 1x1 (SQ->C) + sigmoid.  One block per sample.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_kernel(const SeParams p) {
+    __shared__ float pooled[1152];
+    __shared__ float sq[64];
+    const int b = blockIdx.x;
+    const float* pp = p.pool_partial + (size_t)b * p.S * p.C;
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        float acc = 0.f;
+        for (int s = 0; s < p.S; ++s) acc += pp[(size_t)s * p.C + c];
+        pooled[c] = acc * p.inv_hw;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < p.SQ; j += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < p.C; c += 64) acc = fmaf(p.w1[j * p.C + c], pooled[c], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) sq[j] = swishf(acc + p.b1[j]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        float acc = p.b2[c];
+        for (int j = 0; j < p.SQ; ++j) acc = fmaf(p.w2[c * p.SQ + j], sq[j], acc);
+        p.gate[(size_t)b * p.C + c] = 1.f / (1.f + __expf(-acc));
+    }
+}
+
+void launch_se(const SeParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(se_kernel, dim3(p.B), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ground descriptors: weighted sum over the H_f feature rows, layout d[w*c + ch].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grd_desc_kernel(const GrdDescParams p) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.Ltot) return;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 6; ++j)
+        if (j < p.nlev && i >= p.loff[j]) k = j;
+    const int local = i - p.loff[k];
+    if (local >= p.Wf * p.c[k]) {   // alignment gap between two levels
+        p.desc[(size_t)b * p.Ltot + i] = 0.f;
+        return;
+    }
+    const int w = local / p.c[k];
+    const int ch = local - w * p.c[k];
+    float acc = p.b2[k];
+    const float* y = p.y + ((size_t)b * p.Hf * p.Wf + w) * p.Ntot + p.off[k] + ch;
+    for (int h = 0; h < p.Hf; ++h) acc = fmaf(p.wh[k][h], y[(size_t)h * p.Wf * p.Ntot], acc);
+    p.desc[(size_t)b * p.Ltot + i] = acc;
+}
+
+void launch_grd_desc(const GrdDescParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(grd_desc_kernel, dim3((p.Ltot + 255) / 256, p.B), dim3(256), 0, s, p);
+}
+
+}  // namespace ccvpe

@@ -1,0 +1,203 @@
+// Output-side kernels: the last 3x3 conv of each decoder (16 -> 1 logits, 16 -> 2 orientation with the
+// unit normalisation fused), the 262144-way softmax, the test-loop post-processing and a layout helper.
+//
+// Reference: conv1[2] / conv1_ori[2] (models.py:423-425, 444-446), flatten + Softmax(dim=-1)
+// (models.py:628-629), F.normalize(x_ori, p=2, dim=1) (models.py:650), argmax / (cos,sin) lookup /
+// acos-sign rule (train_VIGOR.py:297-311).
+#include "kernels.h"
+
+namespace ccvpe {
+
+// thread = one output pixel; 9 taps x 16 channels = 4 float4 per tap, NHWC input (64 B per pixel).
+template <int COUT>
+__global__ __launch_bounds__(256) void tail_conv_kernel(const TailConvParams p) {
+    __shared__ float ws[9 * 16 * COUT];
+    for (int i = threadIdx.x; i < 9 * 16 * COUT; i += 256) ws[i] = p.w[i];
+    __syncthreads();
+    const long long total = (long long)p.B * p.H * p.W;
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= total) return;
+    const int x = (int)(pix % p.W);
+    const long long t = pix / p.W;
+    const int y = (int)(t % p.H);
+    const int b = (int)(t / p.H);
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = p.bias[o];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y + ky - 1;
+        if ((unsigned)iy >= (unsigned)p.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = x + kx - 1;
+            if ((unsigned)ix >= (unsigned)p.W) continue;
+            const float* src = p.in + (((size_t)b * p.H + iy) * p.W + ix) * 16;
+            const float* w = ws + (ky * 3 + kx) * 16 * COUT;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const float4 v = *reinterpret_cast<const float4*>(src + c4 * 4);
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) {
+                    acc[o] = fmaf(v.x, w[(c4 * 4 + 0) * COUT + o], acc[o]);
+                    acc[o] = fmaf(v.y, w[(c4 * 4 + 1) * COUT + o], acc[o]);
+                    acc[o] = fmaf(v.z, w[(c4 * 4 + 2) * COUT + o], acc[o]);
+                    acc[o] = fmaf(v.w, w[(c4 * 4 + 3) * COUT + o], acc[o]);
+                }
+            }
+        }
+    }
+    const size_t hw = (size_t)p.H * p.W;
+    const size_t opix = (size_t)y * p.W + x;
+    if (p.raw) {
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) p.raw[((size_t)b * COUT + o) * hw + opix] = acc[o];
+    }
+    if (p.normalize) {
+        float n2 = 0.f;
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) n2 = fmaf(acc[o], acc[o], n2);
+        const float inv = 1.f / fmaxf(sqrtf(n2), 1e-12f);
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] *= inv;
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) p.out[((size_t)b * COUT + o) * hw + opix] = acc[o];
+}
+
+void launch_tail_conv(const TailConvParams& p, hipStream_t s) {
+    long long total = (long long)p.B * p.H * p.W;
+    int blocks = (int)((total + 255) / 256);
+    if (p.cout == 1) hipLaunchKernelGGL(tail_conv_kernel<1>, dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(tail_conv_kernel<2>, dim3(blocks), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Softmax over n = 262144 logits per sample, two launches: per-chunk online (max, sum exp) partials,
+// then every block re-derives the sample's (max, sum) from the partials and normalises its chunk.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void combine(float& m, float& s, float m2, float s2) {
+    const float mn = fmaxf(m, m2);
+    if (mn == -INFINITY) { s = 0.f; return; }   // both sides empty: exp(-inf - -inf) would be NaN
+    s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+}
+
+__global__ __launch_bounds__(256) void softmax_partial_kernel(const SoftmaxParams p) {
+    __shared__ float sm[4], ss[4];
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int per = p.n / p.chunks;
+    const float4* src = reinterpret_cast<const float4*>(p.logits + (size_t)b * p.n + (size_t)ch * per);
+    float m = -INFINITY, s = 0.f;
+    for (int i = threadIdx.x; i < per / 4; i += 256) {
+        const float4 v = src[i];
+        const float lm = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+        const float mn = fmaxf(m, lm);
+        s = s * __expf(m - mn) + __expf(v.x - mn) + __expf(v.y - mn) + __expf(v.z - mn) + __expf(v.w - mn);
+        m = mn;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float m2 = __shfl_xor(m, off), s2 = __shfl_xor(s, off);
+        combine(m, s, m2, s2);
+    }
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = m; ss[threadIdx.x >> 6] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) combine(m, s, sm[w], ss[w]);
+        p.partial[((size_t)b * p.chunks + ch) * 2 + 0] = m;
+        p.partial[((size_t)b * p.chunks + ch) * 2 + 1] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_final_kernel(const SoftmaxParams p) {
+    __shared__ float gm, gs;
+    const int b = blockIdx.y, ch = blockIdx.x;
+    if (threadIdx.x < 64) {
+        float m = -INFINITY, s = 0.f;
+        for (int i = threadIdx.x; i < p.chunks; i += 64)
+            combine(m, s, p.partial[((size_t)b * p.chunks + i) * 2], p.partial[((size_t)b * p.chunks + i) * 2 + 1]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float m2 = __shfl_xor(m, off), s2 = __shfl_xor(s, off);
+            combine(m, s, m2, s2);
+        }
+        if (threadIdx.x == 0) { gm = m; gs = 1.f / s; }
+    }
+    __syncthreads();
+    const float m = gm, inv = gs;
+    const int per = p.n / p.chunks;
+    const float4* src = reinterpret_cast<const float4*>(p.logits + (size_t)b * p.n + (size_t)ch * per);
+    float4* dst = reinterpret_cast<float4*>(p.out + (size_t)b * p.n + (size_t)ch * per);
+    for (int i = threadIdx.x; i < per / 4; i += 256) {
+        const float4 v = src[i];
+        dst[i] = make_float4(__expf(v.x - m) * inv, __expf(v.y - m) * inv, __expf(v.z - m) * inv, __expf(v.w - m) * inv);
+    }
+}
+
+void launch_softmax(const SoftmaxParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_partial_kernel, dim3(p.chunks, p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(softmax_final_kernel, dim3(p.chunks, p.B), dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Post-processing: argmax (first maximal index, as numpy.argmax), prob, (cos, sin), angle in degrees.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void postprocess_kernel(const float* heat, const float* ori, int n, PoseOut* out) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int b = blockIdx.x;
+    const float* h = heat + (size_t)b * n;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float v = h[i];
+        if (v > best) { best = v; bi = i; }   // strictly greater keeps the first index per thread
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float v2 = __shfl_xor(best, off);
+        const int i2 = __shfl_xor(bi, off);
+        if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        const float c = ori[((size_t)b * 2 + 0) * n + bi];
+        const float s = ori[((size_t)b * 2 + 1) * n + bi];
+        float ang = acosf(fminf(fmaxf(c, -1.f), 1.f)) * 57.29577951308232f;
+        if (s < 0.f) { ang = fmodf(-ang, 360.f); if (ang < 0.f) ang += 360.f; }
+        out[b].index = bi;
+        out[b].prob = best;
+        out[b].cos_v = c;
+        out[b].sin_v = s;
+        out[b].angle_deg = ang;
+    }
+}
+
+void launch_postprocess(const float* heat, const float* ori, int B, int n, PoseOut* out, hipStream_t s) {
+    hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(1024), 0, s, heat, ori, n, out);
+}
+
+// NHWC view -> NCHW copy (debug taps only).
+__global__ void nhwc_to_nchw_kernel(const float* in, int in_ld, int coff, int C, int B, int HW, float* out) {
+    const long long total = (long long)B * C * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const long long t = i / HW;
+        const int c = (int)(t % C);
+        const int b = (int)(t / C);
+        out[i] = in[((size_t)b * HW + p) * in_ld + coff + c];
+    }
+}
+
+void launch_nhwc_to_nchw(const float* in, int in_ld, int coff, int C, int B, int HW, float* out, hipStream_t s) {
+    long long total = (long long)B * C * HW;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, in, in_ld, coff, C, B, HW, out);
+}
+
+}  // namespace ccvpe

@@ -1,0 +1,289 @@
+"""Host-side mirror of the reference `models` module for the inference path.
+
+Exports the four classes the reference drivers import (train_VIGOR.py:17-18, train_KITTI.py:17,
+train_OxfordRobotCar.py:17) with the same constructor arguments, the same 818-key `state_dict`
+layout (strict `load_state_dict` of a reference checkpoint succeeds) and the same
+`forward(grd, sat) -> 9-tuple` contract (models.py:150, 448, 752, 1051).  The modules own ordinary
+torch parameters (so `.to()`, `.eval()`, `.state_dict()` behave), but `forward` does not run a
+PyTorch graph: it hands device pointers to libccvpe_hip.so through the C ABI in include/ccvpe.h.
+
+Inference only: no autograd through the HIP path, `eval()` mode required, GPU required.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib, spec
+
+__all__ = ["CVM_VIGOR", "CVM_VIGOR_ori_prior", "CVM_KITTI", "CVM_OxfordRobotCar"]
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers (no forward of their own): they only reproduce the reference key layout
+# ---------------------------------------------------------------------------------------------
+class _Params(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: the forward pass runs in libccvpe_hip.so")
+
+
+def _bn(c: int) -> nn.BatchNorm2d:
+    # momentum = 1 - 0.99, eps 1e-3 (efficientnet_pytorch/model.py:171-172, utils.py:665-666)
+    return nn.BatchNorm2d(c, momentum=0.01, eps=spec.BN_EPS)
+
+
+class _MBConvParams(_Params):
+    """Key layout of MBConvBlock (efficientnet_pytorch/model.py:57-87)."""
+
+    def __init__(self, e: int, k: int, s: int, cin: int, cout: int):
+        super().__init__()
+        mid = cin * e
+        if e != 1:
+            self._expand_conv = nn.Conv2d(cin, mid, 1, bias=False)
+            self._bn0 = _bn(mid)
+        self._depthwise_conv = nn.Conv2d(mid, mid, k, stride=s, groups=mid, bias=False)
+        self._bn1 = _bn(mid)
+        sq = spec.se_squeeze(cin)
+        self._se_reduce = nn.Conv2d(mid, sq, 1)
+        self._se_expand = nn.Conv2d(sq, mid, 1)
+        self._project_conv = nn.Conv2d(mid, cout, 1, bias=False)
+        self._bn2 = _bn(cout)
+
+
+class _EfficientNetParams(_Params):
+    """Key layout of EfficientNet-B0 as CCVPE builds it (efficientnet_pytorch/model.py:162-219)."""
+
+    def __init__(self):
+        super().__init__()
+        self._conv_stem = nn.Conv2d(3, spec.STEM_CH, 3, stride=2, bias=False)
+        self._bn0 = _bn(spec.STEM_CH)
+        self._blocks = nn.ModuleList([_MBConvParams(*b) for b in spec.B0_BLOCKS])
+        self._conv_head = nn.Conv2d(spec.B0_BLOCKS[-1][4], spec.HEAD_CH, 1, bias=False)
+        self._bn1 = _bn(spec.HEAD_CH)
+        self._fc = nn.Linear(spec.HEAD_CH, spec.FC_CLASSES)   # unused by CCVPE, present in checkpoints
+
+
+def _double_conv(cin: int, mid: int, cout: int) -> nn.Sequential:
+    return nn.Sequential(nn.Conv2d(cin, mid, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(mid, cout, 3, padding=1))
+
+
+class _CVMBase(nn.Module):
+    _variant: str = ""
+
+    def __init__(self, device, circular_padding: bool = False, ori_noise: Optional[float] = None,
+                 micro_batch: int = 0):
+        super().__init__()
+        v = spec.VARIANTS[self._variant]
+        self.device = device
+        self.circular_padding = bool(circular_padding)
+        self.ori_noise = ori_noise
+        self._micro_batch = int(micro_batch)
+
+        self.grd_efficientnet = _EfficientNetParams()
+        for lvl, c in enumerate(v.head_ch, 1):
+            setattr(self, f"grd_feature_to_descriptor{lvl}", nn.Sequential(
+                nn.Conv2d(spec.HEAD_CH, c, 1), nn.Identity(), nn.Conv2d(v.feat_h, 1, 1), nn.Flatten(start_dim=1)))
+        self.sat_efficientnet = _EfficientNetParams()
+        self.sat_feature_to_descriptors = nn.Sequential(nn.Flatten(start_dim=1), nn.Linear(spec.HEAD_CH * 4, v.sat_desc))
+        for sfx, dec in (("", v.loc), ("_ori", v.ori)):
+            for j, lv in enumerate(dec):
+                n = 6 - j
+                setattr(self, f"deconv{n}{sfx}", nn.ConvTranspose2d(lv.deconv_in, lv.deconv_out, 2, 2))
+                setattr(self, f"conv{n}{sfx}", _double_conv(lv.deconv_out + lv.skip, lv.mid, lv.out))
+
+        self._handle: Optional[C.c_void_p] = None
+        self._handle_device: Optional[int] = None
+        self._weights_dirty = True
+        self._debug = False
+        self._rolls: Tuple[int, ...] = ()
+
+    # ---- lifetime of the native handle ------------------------------------------------------
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            try:
+                _lib.load().ccvpe_destroy(self._handle)
+            finally:
+                self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _apply(self, fn, *a, **k):       # .to() / .cuda() / .cpu() move the parameters
+        out = super()._apply(fn, *a, **k)
+        self._weights_dirty = True
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, *a, **k):
+        out = super().load_state_dict(state_dict, strict, *a, **k)
+        self._weights_dirty = True
+        return out
+
+    def refresh_weights(self) -> None:
+        """Call after modifying parameters in place: the next forward re-ingests the state_dict."""
+        self._weights_dirty = True
+
+    def _ensure_handle(self, dev: torch.device) -> None:
+        lib = _lib.load()
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        if self._handle is not None and self._handle_device != index:
+            self._release()
+        if self._handle is None:
+            cfg = _lib.Config()
+            cfg.variant = _lib.VARIANT_ID[self._variant]
+            cfg.circular_padding = int(self.circular_padding)
+            cfg.ori_noise = float(self.ori_noise) if self.ori_noise is not None else 0.0
+            cfg.device = index
+            cfg.micro_batch = self._micro_batch
+            h = C.c_void_p()
+            _lib.check(lib.ccvpe_create(C.byref(cfg), C.byref(h)), "ccvpe_create")
+            self._handle, self._handle_device = h, index
+            self._weights_dirty = True
+            self._rolls = tuple(lib.ccvpe_output_channels(h, k) for k in range(6))
+            if self._debug:
+                _lib.check(lib.ccvpe_set_debug(h, 1), "ccvpe_set_debug")
+        if self._weights_dirty:
+            for key, t in self.state_dict().items():
+                if t.dtype != torch.float32 or "._fc." in key:
+                    _lib.check(lib.ccvpe_skip_weight(self._handle, key.encode()), f"ccvpe_skip_weight({key})")
+                    continue
+                t = t.detach().contiguous()
+                shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+                _lib.check(lib.ccvpe_set_weight(self._handle, key.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()),
+                           f"ccvpe_set_weight({key})")
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            _lib.check(lib.ccvpe_finalize_weights(self._handle), "ccvpe_finalize_weights")
+            self._weights_dirty = False
+
+    # ---- forward ----------------------------------------------------------------------------
+    def _prepare(self, grd: torch.Tensor, sat: torch.Tensor):
+        if self.training:
+            raise RuntimeError("ccvpe_amd runs the inference path only: call .eval() first "
+                               "(reference test loops do, train_VIGOR.py:254)")
+        if not (grd.is_cuda and sat.is_cuda):
+            raise RuntimeError("ccvpe_amd has no CPU path: inputs must live on an MI355X (cuda) device")
+        if grd.device != sat.device:
+            raise RuntimeError("grd and sat must be on the same device")
+        if grd.dim() != 4 or sat.dim() != 4 or grd.shape[1] != 3 or sat.shape[1] != 3 or grd.shape[0] != sat.shape[0]:
+            raise ValueError(f"expected grd [B,3,H,W] and sat [B,3,512,512], got {tuple(grd.shape)} / {tuple(sat.shape)}")
+        if tuple(sat.shape[2:]) != spec.SAT_HW:
+            raise ValueError(f"aerial input must be 3x512x512, got {tuple(sat.shape)}")
+        grd = grd.detach().to(torch.float32).contiguous()
+        sat = sat.detach().to(torch.float32).contiguous()
+        self._ensure_handle(grd.device)
+        return grd, sat
+
+    def _alloc_outputs(self, B: int, dev: torch.device):
+        n = spec.OUT_HW[0] * spec.OUT_HW[1]
+        logits = torch.empty((B, n), dtype=torch.float32, device=dev)
+        heat = torch.empty((B, 1) + spec.OUT_HW, dtype=torch.float32, device=dev)
+        ori = torch.empty((B, 2) + spec.OUT_HW, dtype=torch.float32, device=dev)
+        ms = [torch.empty((B, self._rolls[k], 8 << k, 8 << k), dtype=torch.float32, device=dev) for k in range(6)]
+        out = _lib.Outputs()
+        out.logits_flattened = logits.data_ptr()
+        out.heatmap = heat.data_ptr()
+        out.ori = ori.data_ptr()
+        for k in range(6):
+            out.matching_score[k] = ms[k].data_ptr()
+        return out, (logits, heat, ori, *ms)
+
+    def forward(self, grd: torch.Tensor, sat: torch.Tensor):
+        grd, sat = self._prepare(grd, sat)
+        B = grd.shape[0]
+        with torch.cuda.device(grd.device):
+            out, tensors = self._alloc_outputs(B, grd.device)
+            stream = torch.cuda.current_stream(grd.device).cuda_stream
+            rc = _lib.load().ccvpe_forward(self._handle, C.c_void_p(grd.data_ptr()), grd.shape[2], grd.shape[3],
+                                           C.c_void_p(sat.data_ptr()), B, C.byref(out), C.c_void_p(stream))
+        _lib.check(rc, "ccvpe_forward")
+        return tensors
+
+    # ---- extras beyond the reference surface ------------------------------------------------
+    def postprocess(self, heatmap: torch.Tensor, ori: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Device-side version of the per-sample loop in train_VIGOR.py:297-316."""
+        B = heatmap.shape[0]
+        self._ensure_handle(heatmap.device)
+        buf = torch.empty((B, 5), dtype=torch.int32, device=heatmap.device)
+        stream = torch.cuda.current_stream(heatmap.device).cuda_stream
+        rc = _lib.load().ccvpe_postprocess(self._handle, C.c_void_p(heatmap.contiguous().data_ptr()),
+                                           C.c_void_p(ori.contiguous().data_ptr()), B, C.c_void_p(buf.data_ptr()),
+                                           C.c_void_p(stream))
+        _lib.check(rc, "ccvpe_postprocess")
+        f = buf.view(torch.float32)
+        return {"index": buf[:, 0].to(torch.int64), "prob": f[:, 1], "cos": f[:, 2], "sin": f[:, 3], "angle_deg": f[:, 4]}
+
+    def set_debug(self, enable: bool) -> None:
+        self._debug = bool(enable)
+        if self._handle is not None:
+            _lib.check(_lib.load().ccvpe_set_debug(self._handle, int(enable)), "ccvpe_set_debug")
+
+    def read_tap(self, name: str) -> torch.Tensor:
+        """Intermediate tensor of the last debug forward as NCHW float32 on the CPU."""
+        lib = _lib.load()
+        cap = 64 * 1024 * 1024
+        while True:
+            host = torch.empty(cap, dtype=torch.float32)
+            n = C.c_size_t(0)
+            shape = (C.c_int32 * 4)()
+            rc = lib.ccvpe_read_tap(self._handle, name.encode(), C.c_void_p(host.data_ptr()), cap, C.byref(n), C.byref(shape))
+            if rc == -1 and b"needs" in (lib.ccvpe_last_error() or b""):
+                cap *= 4
+                continue
+            _lib.check(rc, f"ccvpe_read_tap({name})")
+            return host[: n.value].reshape(*[int(s) for s in shape]).clone()
+
+    def profile(self, grd: torch.Tensor, sat: torch.Tensor):
+        """One forward with a hipEvent pair around every launch: list of (name, ms, flops, bytes)."""
+        grd, sat = self._prepare(grd, sat)
+        B = grd.shape[0]
+        lib = _lib.load()
+        out, _ = self._alloc_outputs(B, grd.device)
+        stream = torch.cuda.current_stream(grd.device).cuda_stream
+        n = lib.ccvpe_profile_forward(self._handle, C.c_void_p(grd.data_ptr()), grd.shape[2], grd.shape[3],
+                                      C.c_void_p(sat.data_ptr()), B, C.byref(out), C.c_void_p(stream))
+        _lib.check(n, "ccvpe_profile_forward")
+        rows = []
+        name = C.create_string_buffer(128)
+        ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+        for i in range(n):
+            _lib.check(lib.ccvpe_profile_row(self._handle, i, name, 128, C.byref(ms), C.byref(fl), C.byref(by)), "ccvpe_profile_row")
+            rows.append((name.value.decode(), ms.value, fl.value, by.value))
+        return rows
+
+
+class CVM_VIGOR(_CVMBase):
+    """models.py:49 - CVM_VIGOR(device, circular_padding)."""
+    _variant = "vigor"
+
+    def __init__(self, device, circular_padding, **kw):
+        super().__init__(device, circular_padding, None, **kw)
+
+
+class CVM_VIGOR_ori_prior(_CVMBase):
+    """models.py:346 - CVM_VIGOR_ori_prior(device, ori_noise, circular_padding=True)."""
+    _variant = "vigor_ori_prior"
+
+    def __init__(self, device, ori_noise, circular_padding=True, **kw):
+        super().__init__(device, circular_padding, ori_noise, **kw)
+
+
+class CVM_KITTI(_CVMBase):
+    """models.py:655 - CVM_KITTI(device); no circular padding (models.py:660)."""
+    _variant = "kitti"
+
+    def __init__(self, device, **kw):
+        super().__init__(device, False, None, **kw)
+
+
+class CVM_OxfordRobotCar(_CVMBase):
+    """models.py:954 - CVM_OxfordRobotCar(device)."""
+    _variant = "oxford"
+
+    def __init__(self, device, **kw):
+        super().__init__(device, False, None, **kw)

@@ -106,7 +106,8 @@ def generate_state_dict_numpy(variant: str, seed: int = 0) -> Dict[str, np.ndarr
 def generate_state_dict(variant: str, seed: int = 0):
     """Same values as torch tensors (CPU)."""
     import torch
-    return {k: torch.from_numpy(np.ascontiguousarray(a)) for k, a in generate_state_dict_numpy(variant, seed).items()}
+    return {k: (torch.from_numpy(np.ascontiguousarray(a)) if a.ndim else torch.tensor(int(a), dtype=torch.int64))
+            for k, a in generate_state_dict_numpy(variant, seed).items()}
 
 
 def generate_inputs(variant: str, batch: int, seed: int = 0, fov: float = 360.0):

@@ -1,0 +1,131 @@
+/*
+ * ccvpe.h - C ABI of libccvpe_hip.so: the MI355X (gfx950) inference forward pass of CCVPE.
+ *
+ * The reference is pure Python/PyTorch and has no native interface of its own; the hot path it
+ * exposes is `CVM_*.forward(grd, sat)` (reference models.py:150, 448, 752, 1051) on an nn.Module
+ * whose parameters arrive through `load_state_dict` (reference train_VIGOR.py:248-254).  This
+ * header is what a binding for that path binds:
+ *
+ *   reference interface                                   replaced by
+ *   ----------------------------------------------------  -----------------------------------------
+ *   CVM_VIGOR(device, circular_padding)        models.py:50    ccvpe_create (variant 0)
+ *   CVM_VIGOR_ori_prior(device, ori_noise, circ) models.py:347 ccvpe_create (variant 1)
+ *   CVM_KITTI(device)                          models.py:656   ccvpe_create (variant 2)
+ *   CVM_OxfordRobotCar(device)                 models.py:955   ccvpe_create (variant 3)
+ *   load_state_dict(state_dict)          train_VIGOR.py:252    ccvpe_set_weight x818 + ccvpe_finalize_weights
+ *   forward(grd, sat) -> 9-tuple   models.py:150,448,752,1051  ccvpe_forward
+ *   per-sample argmax / (cos,sin) lookup train_VIGOR.py:297-316 ccvpe_postprocess
+ *
+ * Conventions
+ *   - all tensors are float32; inputs/outputs are NCHW-contiguous exactly as the reference's
+ *     forward receives and returns them; pointers are DEVICE pointers borrowed from the caller
+ *     (e.g. torch.Tensor.data_ptr()) and are never freed or retained by the library;
+ *   - every function returns 0 on success or a negative CCVPE_E* code; ccvpe_last_error() gives
+ *     a thread-local human-readable message; nothing throws across the ABI;
+ *   - a handle is bound to one HIP device and is not re-entrant; launches go to the caller's
+ *     stream, asynchronously, with no hidden synchronisation once the plan for a given
+ *     (batch, ground size) exists (the first call with a new shape allocates workspace);
+ *   - there is no CPU fallback: without a gfx950 device every compute entry point fails.
+ */
+#ifndef CCVPE_H
+#define CCVPE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCVPE_OK 0
+#define CCVPE_EINVAL (-1)   /* bad argument / shape */
+#define CCVPE_ESTATE (-2)   /* call order (e.g. forward before finalize) */
+#define CCVPE_EHIP (-3)     /* HIP runtime error */
+#define CCVPE_ENOMEM (-4)
+#define CCVPE_EKEY (-5)     /* unknown / missing state_dict key */
+
+#define CCVPE_VARIANT_VIGOR 0
+#define CCVPE_VARIANT_VIGOR_ORI_PRIOR 1
+#define CCVPE_VARIANT_KITTI 2
+#define CCVPE_VARIANT_OXFORD 3
+
+#define CCVPE_OUT_HW 512       /* localisation / orientation maps are 512 x 512 (models.py:319-341) */
+#define CCVPE_SAT_HW 512       /* aerial input is 3 x 512 x 512 */
+
+typedef struct ccvpe_handle_s* ccvpe_handle;
+
+typedef struct ccvpe_config {
+    int32_t variant;            /* CCVPE_VARIANT_* */
+    int32_t circular_padding;   /* ground encoder: horizontal circular padding (models.py:53, utils.py:330-358) */
+    float   ori_noise;          /* variant 1 only: rolls i = -n..n, n = int(ori_noise/18) (models.py:489) */
+    int32_t device;             /* HIP device ordinal */
+    int32_t micro_batch;        /* samples per internal pass (0 = library default); larger batches loop */
+    int32_t reserved[3];
+} ccvpe_config;
+
+/* Caller-allocated outputs of one forward call (device memory, NCHW contiguous, batch-major).
+ * Channel counts of ms[k] come from ccvpe_output_channels(). */
+typedef struct ccvpe_outputs {
+    float* logits_flattened;    /* [B, 512*512]                                  models.py:319 */
+    float* heatmap;             /* [B, 1, 512, 512] softmax over all pixels       models.py:320 */
+    float* ori;                 /* [B, 2, 512, 512] unit (cos, sin) field         models.py:341 */
+    float* matching_score[6];   /* level k: [B, R_k, 8*2^k, 8*2^k], k = 0..5      models.py:343 */
+} ccvpe_outputs;
+
+/* Compact per-sample result of the test-loop post-processing (train_VIGOR.py:297-316). */
+typedef struct ccvpe_pose {
+    int32_t index;              /* argmax of the heatmap, y*512 + x */
+    float   prob;               /* heatmap value there */
+    float   cos_v, sin_v;       /* orientation field at that pixel */
+    float   angle_deg;          /* acos/sign rule of train_VIGOR.py:307-311, in [0, 360) */
+} ccvpe_pose;
+
+const char* ccvpe_last_error(void);
+const char* ccvpe_version(void);
+
+int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out);
+int ccvpe_destroy(ccvpe_handle h);
+
+/* One state_dict entry.  `data` may be a host or a device pointer (float32, contiguous, `shape`
+ * as in the reference state_dict); BatchNorm `num_batches_tracked` (int64) entries and the unused
+ * `_fc.*` classifier are accepted and ignored via ccvpe_skip_weight.  Returns CCVPE_EKEY for a key
+ * that is not part of the 818-key layout, CCVPE_EINVAL for a shape mismatch. */
+int ccvpe_set_weight(ccvpe_handle h, const char* key, const float* data, const int64_t* shape, int32_t ndim);
+int ccvpe_skip_weight(ccvpe_handle h, const char* key);
+/* Folds BatchNorm into the adjacent convolutions, repacks everything into the kernels' layouts and
+ * uploads it.  Fails with CCVPE_EKEY (message lists the first missing key) if any key is unset. */
+int ccvpe_finalize_weights(ccvpe_handle h);
+
+/* R_k of matching_score[level] (level 0..5) for this handle's variant / ori_noise. */
+int ccvpe_output_channels(ccvpe_handle h, int32_t level);
+/* Device workspace the library holds for a (batch, ground size) plan, in bytes (0 on error). */
+size_t ccvpe_workspace_bytes(ccvpe_handle h, int32_t batch, int32_t grd_h, int32_t grd_w);
+
+/* forward(grd, sat): grd [B,3,grd_h,grd_w], sat [B,3,512,512], device pointers, NCHW float32.
+ * `stream` is a hipStream_t (NULL = default stream). */
+int ccvpe_forward(ccvpe_handle h, const float* grd, int32_t grd_h, int32_t grd_w, const float* sat,
+                  int32_t batch, const ccvpe_outputs* out, void* stream);
+
+/* Device-side test-loop post-processing on forward outputs: poses[B] is DEVICE memory. */
+int ccvpe_postprocess(ccvpe_handle h, const float* heatmap, const float* ori, int32_t batch,
+                      ccvpe_pose* poses, void* stream);
+
+/* Debug taps: when enabled, intermediate tensors of the next forward call stay resident and can be
+ * copied out by name as NCHW float32 into HOST memory (`capacity` in floats).  Returns the number
+ * of floats written via *n_out.  Names: see DESIGN.md (e.g. "sat_block15", "loc_level6"). */
+int ccvpe_set_debug(ccvpe_handle h, int32_t enable);
+int ccvpe_read_tap(ccvpe_handle h, const char* name, float* host_dst, size_t capacity, size_t* n_out,
+                   int32_t shape_out[4]);
+
+/* Per-kernel device timing of the most recent ccvpe_profile_forward call: runs one forward with a
+ * hipEvent pair around every launch and reports (name, milliseconds) rows.  Used by bench.py for
+ * the roofline line.  Returns the number of rows; row i is copied into name_buf / ms. */
+int ccvpe_profile_forward(ccvpe_handle h, const float* grd, int32_t grd_h, int32_t grd_w, const float* sat,
+                          int32_t batch, const ccvpe_outputs* out, void* stream);
+int ccvpe_profile_row(ccvpe_handle h, int32_t i, char* name_buf, size_t name_cap, float* ms,
+                      double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCVPE_H */
