@@ -931,13 +931,17 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
             HIPCHK(hipEventCreate(&e0));
             HIPCHK(hipEventCreate(&e1));
             for (auto& op : pl->ops) {
+                (void)conv_igemm_last_tile();
                 HIPCHK(hipEventRecord(e0, stream));
                 op.fn(c);
                 HIPCHK(hipEventRecord(e1, stream));
                 HIPCHK(hipEventSynchronize(e1));
                 float ms = 0.f;
                 HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-                h->prof.push_back({op.name, ms, op.flops, op.bytes});
+                const int tile = conv_igemm_last_tile();
+                std::string nm = op.name;
+                if (tile) nm += std::string("|") + conv_igemm_tile_name(tile);
+                h->prof.push_back({nm, ms, op.flops, op.bytes});
             }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);

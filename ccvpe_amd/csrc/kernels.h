@@ -48,6 +48,8 @@ struct ConvParams {
 enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_128x32 = 4 };
 void launch_conv_igemm(const ConvParams& p, int tile, hipStream_t s);
 int conv_igemm_npad();       // row padding of packed weights (multiple every tile divides)
+int conv_igemm_last_tile();  // tile id of the most recent launch on this thread (then reset to 0)
+const char* conv_igemm_tile_name(int tile);
 
 // ---------------------------------------------------------------------------------------------
 // Encoder pieces

@@ -239,8 +239,21 @@ static int pick_tile(const ConvParams& p) {
     return best;
 }
 
+static thread_local int g_last_tile = 0;
+int conv_igemm_last_tile() { int t = g_last_tile; g_last_tile = 0; return t; }
+const char* conv_igemm_tile_name(int tile) {
+    switch (tile) {
+        case TILE_128x128: return "conv_igemm_128x128";
+        case TILE_128x64: return "conv_igemm_128x64";
+        case TILE_64x64: return "conv_igemm_64x64";
+        case TILE_128x32: return "conv_igemm_128x32";
+        default: return "";
+    }
+}
+
 void launch_conv_igemm(const ConvParams& p, int tile, hipStream_t s) {
     if (tile == TILE_AUTO) tile = pick_tile(p);
+    g_last_tile = tile;
     switch (tile) {
         case TILE_128x128: launch_cfg<128, 128, 2, 2>(p, s); break;
         case TILE_128x64:  launch_cfg<128, 64, 2, 2>(p, s); break;

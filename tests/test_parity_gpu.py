@@ -1,0 +1,162 @@
+"""Parity of the HIP path (through the C ABI) against the reference golden vectors and the CPU oracle.
+
+Tolerance: BASELINE.json north_star asks for 1e-3 relative fp32; errors are measured relative to each
+tensor's max |value|.  The fp32-MFMA path is exact fp32 arithmetic, so we hold it to 1e-4 - tighter
+than the contract - and the contract bound is asserted separately.
+"""
+import numpy as np
+import pytest
+import torch
+
+from ccvpe_amd import models, weights
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+CONTRACT_RTOL = 1e-3
+RTOL = 1e-4
+
+
+def build_model(cfg, micro_batch=0):
+    v = cfg["variant"]
+    if v == "vigor":
+        m = models.CVM_VIGOR("cuda", cfg["circular"], micro_batch=micro_batch)
+    elif v == "vigor_ori_prior":
+        m = models.CVM_VIGOR_ori_prior("cuda", cfg["ori_noise"], cfg["circular"], micro_batch=micro_batch)
+    elif v == "kitti":
+        m = models.CVM_KITTI("cuda", micro_batch=micro_batch)
+    else:
+        m = models.CVM_OxfordRobotCar("cuda", micro_batch=micro_batch)
+    m.load_state_dict(weights.generate_state_dict(v, cfg["seed"]))
+    return m.to("cuda").eval()
+
+
+def inputs(cfg, batch=None):
+    g, s = weights.generate_inputs(cfg["variant"], batch or cfg["batch"], cfg["seed"], cfg["fov"])
+    return torch.from_numpy(g).cuda(), torch.from_numpy(s).cuda()
+
+
+def check_against_fixture(fx, outs, rtol):
+    worst = 0.0
+    for n, t in zip(gu.OUTPUT_NAMES, outs):
+        if n == "ori":
+            continue
+        worst = max(worst, gu.compare(n, fx, t.cpu().numpy(), rtol))
+    ori = outs[2].cpu().numpy().reshape(-1)
+    idx = gu.lattice(ori.size)
+    mag = fx["ori/magnitude"].astype(np.float64)
+    err = (np.abs(ori[idx].astype(np.float64) - fx["ori/values"].astype(np.float64)) * mag).max() / mag.max()
+    assert err <= rtol, f"ori: magnitude-weighted error {err:.3g}"
+    return max(worst, err)
+
+
+@pytest.mark.parametrize("name", list(gu.CONFIGS))
+def test_forward_matches_reference_golden(name):
+    cfg = gu.CONFIGS[name]
+    fx = gu.load(name)
+    m = build_model(cfg)
+    g, s = inputs(cfg)
+    outs = m(g, s)
+    assert len(outs) == 9 and all(o.is_cuda and o.dtype == torch.float32 for o in outs)
+    worst = check_against_fixture(fx, outs, RTOL)
+    assert worst <= CONTRACT_RTOL
+    # outputs are fresh tensors owned by the caller (a second call must not alias them)
+    again = m(g, s)
+    assert again[0].data_ptr() != outs[0].data_ptr()
+    assert torch.equal(again[0], outs[0]), "forward is deterministic run to run"
+    # test-loop post-processing on device vs the reference's numpy result
+    post = m.postprocess(outs[1], outs[2])
+    assert np.array_equal(post["index"].cpu().numpy(), fx["post/index"])
+    assert np.allclose(post["prob"].cpu().numpy(), fx["post/prob"], rtol=1e-3)
+    assert np.allclose(post["cos"].cpu().numpy(), fx["post/cos"], atol=2e-3)
+    assert np.allclose(post["sin"].cpu().numpy(), fx["post/sin"], atol=2e-3)
+
+
+def test_intermediate_taps_match_reference_golden():
+    cfg = gu.CONFIGS["vigor_prior180_circ"]
+    fx = gu.load("vigor_prior180_circ")
+    m = build_model(cfg)
+    m.set_debug(True)
+    g, s = inputs(cfg)
+    m(g, s)
+    for tap in ["sat_block0", "sat_block2", "sat_block4", "sat_block10", "sat_block15", "grd_desc1", "grd_desc3", "grd_desc6",
+                "loc_level6", "loc_level4", "loc_level2", "ori_level6", "ori_level3"]:
+        t = m.read_tap(tap).numpy()
+        if tap.startswith("grd_desc"):
+            t = t.reshape(t.shape[0], -1)
+        gu.compare("tap_" + tap, fx, t, RTOL)
+    gu.compare("tap_ori_level1", fx, m.read_tap("ori_level1_nchw").numpy(), RTOL)
+
+
+def test_full_tensor_against_oracle_oxford():
+    """Full-tensor comparison (not just the lattice) on the smallest-ground variant, odd image sizes."""
+    from oracle import ccvpe_oracle as orc
+    cfg = gu.CONFIGS["oxford"]
+    sd = weights.generate_state_dict("oxford", 11)
+    g, s = weights.generate_inputs("oxford", 2, 11)
+    ref = orc.forward("oxford", sd, torch.from_numpy(g), torch.from_numpy(s))
+    m = models.CVM_OxfordRobotCar("cuda")
+    m.load_state_dict(sd)
+    m.to("cuda").eval()
+    outs = m(torch.from_numpy(g).cuda(), torch.from_numpy(s).cuda())
+    for i, (a, b) in enumerate(zip(ref, outs)):
+        if i == 2:
+            continue
+        err = (a - b.cpu()).abs().max().item() / a.abs().max().item()
+        assert err <= RTOL, f"{gu.OUTPUT_NAMES[i]}: {err:.3g}"
+
+
+def test_batch32_properties_and_micro_batching():
+    """BASELINE config 2 shape (B=32): size-independent properties + consistency with B=1 and with
+    an internal micro-batch that does not divide the batch."""
+    cfg = gu.CONFIGS["vigor_prior180_circ"]
+    m = build_model(cfg)
+    g, s = inputs(cfg, batch=32)
+    outs = m(g, s)
+    logits, heat, ori = outs[0], outs[1], outs[2]
+    assert torch.isfinite(logits).all()
+    sums = heat.double().sum(dim=(1, 2, 3))
+    assert torch.allclose(sums, torch.ones_like(sums), atol=1e-4), "softmax over 512*512 sums to 1 per sample"
+    assert torch.allclose(heat.flatten(1), torch.softmax(logits, dim=1), rtol=2e-4, atol=1e-9)
+    norm = ori.double().pow(2).sum(dim=1).sqrt()
+    assert (norm - 1).abs().max().item() < 1e-4, "orientation field is unit-norm everywhere"
+    for k in range(6):
+        assert outs[3 + k].abs().max().item() <= 1.0 + 1e-5, "cosine scores are bounded by 1"
+    # sample 0 of the generator at batch 32 == the single golden sample (same seed, same first draw?) - use B=1 run instead
+    one = m(g[5:6], s[5:6])
+    for a, b in zip(outs, one):
+        assert (a[5:6] - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-30), "batch-size invariance"
+    # permutation equivariance
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(1)).cuda()
+    outs_p = m(g[perm], s[perm])
+    assert (outs_p[0] - logits[perm]).abs().max().item() <= 2e-5 * logits.abs().max().item()
+    # micro-batch 5 (32 = 6*5 + 2): looped passes must agree with the single pass
+    m5 = build_model(cfg, micro_batch=5)
+    outs5 = m5(g, s)
+    for a, b in zip(outs, outs5):
+        assert (a - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1e-30)
+
+
+def test_argument_errors_are_loud():
+    cfg = gu.CONFIGS["kitti"]
+    m = build_model(cfg)
+    g, s = inputs(cfg)
+    with pytest.raises(RuntimeError):
+        m(g[:, :, :250], s)            # ground height that does not give 8 feature rows
+    with pytest.raises(ValueError):
+        m(g, s[:, :, :256, :256])
+    with pytest.raises(RuntimeError):
+        m(g.cpu(), s.cpu())
+
+
+def test_reload_state_dict_changes_result():
+    cfg = gu.CONFIGS["oxford"]
+    m = build_model(cfg)
+    g, s = inputs(cfg)
+    a = m(g, s)[0].clone()
+    m.load_state_dict(weights.generate_state_dict("oxford", 99))
+    b = m(g, s)[0]
+    assert not torch.allclose(a, b)
+    m.load_state_dict(weights.generate_state_dict("oxford", cfg["seed"]))
+    c = m(g, s)[0]
+    assert torch.equal(a, c)
