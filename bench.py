@@ -59,14 +59,28 @@ def build_model(variant, kw, dev, micro_batch):
     return m.to(dev).eval()
 
 
-def cpu_baseline(variant, kw, fov, budget_s=20.0):
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (os.cpu_count()
+    reports the host's cores on a shared box and oversubscribes the intra-op pool badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(variant, kw, fov, budget_s=15.0):
     """The oracle (CPU port of the reference graph, proven equal to it in the build container) on the
-    host cores.  Bounded sample: batch-4 forwards until ~budget_s of CPU time has been spent."""
+    host cores.  Bounded sample: batch-2 forwards until ~budget_s of wall time has been spent."""
     from oracle import ccvpe_oracle as orc   # checker / baseline only - never on the product path
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     sd = weights.generate_state_dict(variant, 0)
-    b = 4
+    b = 2
     g, s = weights.generate_inputs(variant, b, 0, fov)
     g, s = torch.from_numpy(g), torch.from_numpy(s)
     orc.forward(variant, sd, g[:1], s[:1], kw.get("circular_padding", False), kw.get("ori_noise"))   # warm-up

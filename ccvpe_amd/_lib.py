@@ -47,7 +47,31 @@ SYMBOLS = [
                                         C.POINTER(Outputs), C.c_void_p]),
     ("ccvpe_profile_row", C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_float),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("ccvpe_op_conv2d", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_void_p]),
 ]
+
+
+def op_conv2d(x_nhwc, w, bias=None, stride=1, pad=0, act=0, tile=0, iters=0):
+    """Kernel-level hook: x [B,H,W,Cin] cuda fp32, w [Cout,Cin,KH,KW], returns (out NHWC, mean ms or None)."""
+    import torch
+    lib = load()
+    B, H, W, Cin = x_nhwc.shape
+    Cout, _, KH, KW = w.shape
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    out = torch.empty((B, OH, OW, Cout), dtype=torch.float32, device=x_nhwc.device)
+    x_nhwc = x_nhwc.contiguous()
+    w = w.contiguous().float()
+    b = bias.contiguous().float() if bias is not None else None
+    ms = C.c_float(0.0)
+    stream = torch.cuda.current_stream(x_nhwc.device).cuda_stream
+    rc = lib.ccvpe_op_conv2d(C.c_void_p(x_nhwc.data_ptr()), B, H, W, Cin, C.c_void_p(w.data_ptr()),
+                             C.c_void_p(b.data_ptr()) if b is not None else None, Cout, KH, KW, stride, pad, act, tile,
+                             C.c_void_p(out.data_ptr()), iters, C.byref(ms), C.c_void_p(stream))
+    check(rc, "ccvpe_op_conv2d")
+    return out, (ms.value if iters > 0 else None)
 
 _lib = None
 

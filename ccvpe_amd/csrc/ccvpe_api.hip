@@ -489,12 +489,13 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
             }, 2.0 * B * oh * ow * mid * b.k * b.k, 4.0 * B * mid * ((double)ch * cw + (double)oh * ow));
         }
         Tensor gate = pl.alloc(B, 1, 1, mid);
+        Tensor pooled = pl.alloc(B, 1, 1, mid);
         {
             SeParams sp{};
             sp.B = B; sp.S = S; sp.C = mid; sp.SQ = bw.sq; sp.inv_hw = 1.f / (float)(oh * ow);
             sp.w1 = bw.se_w1; sp.b1 = bw.se_b1; sp.w2 = bw.se_w2; sp.b2 = bw.se_b2;
-            pl.add(bn + ".se", {pool, gate}, [=](const Ctx& c) {
-                SeParams q = sp; q.pool_partial = c.ptr(pool); q.gate = c.ptr(gate);
+            pl.add(bn + ".se", {pool, gate, pooled}, [=](const Ctx& c) {
+                SeParams q = sp; q.pool_partial = c.ptr(pool); q.gate = c.ptr(gate); q.pooled = c.ptr(pooled);
                 launch_se(q, c.stream);
             }, 4.0 * B * mid * bw.sq, 4.0 * B * S * mid);
         }
@@ -1023,6 +1024,51 @@ int ccvpe_read_tap(ccvpe_handle h, const char* name, float* host_dst, size_t cap
     if (e != hipSuccess) return fail(CCVPE_EHIP, "tap copy failed: %s", hipGetErrorString(e));
     if (n_out) *n_out = n;
     if (shape_out) { shape_out[0] = t.B; shape_out[1] = ti.C; shape_out[2] = t.H; shape_out[3] = t.W; }
+    return 0;
+}
+
+int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w, const float* bias,
+                    int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t act, int32_t tile,
+                    float* out, int32_t iters, float* ms, void* stream) {
+    if (!in || !w || !out) return fail(CCVPE_EINVAL, "null argument");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 8 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+        return fail(CCVPE_EINVAL, "bad conv geometry (Cin must be a multiple of 8)");
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return fail(CCVPE_EINVAL, "empty output");
+    if ((double)B * H * W * Cin >= 2147483647.0 || (double)B * OH * OW * Cout >= 2147483647.0)
+        return fail(CCVPE_EINVAL, "tensor exceeds 2^31 elements");
+    const size_t nw = (size_t)Cout * Cin * KH * KW;
+    std::vector<float> hw(nw), hb(Cout, 0.f);
+    HIPCHK(hipMemcpy(hw.data(), w, nw * sizeof(float), hipMemcpyDefault));
+    if (bias) HIPCHK(hipMemcpy(hb.data(), bias, Cout * sizeof(float), hipMemcpyDefault));
+    ccvpe_handle_s tmp;   // only its dev_allocs list is used by the packer
+    PackedConv pc;
+    const int taps = KH * KW;
+    int rc = pack_conv(&tmp, pc, Cout, taps, Cin, Cin, identity_map(Cin),
+                       [&](int n, int t, int c) { return hw[((size_t)n * Cin + c) * taps + t]; }, hb, KH, KW);
+    auto cleanup = [&]() { for (void* p : tmp.dev_allocs) (void)hipFree(p); };
+    if (rc) { cleanup(); return rc; }
+    ConvParams p = conv_params(pc, in, Cin, B, H, W, OH, OW, stride, pad, pad, act);
+    p.dst[0] = {out, Cout, 0}; p.ndst = 1;
+    hipStream_t st = (hipStream_t)stream;
+    launch_conv_igemm(p, tile, st);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && iters > 0 && ms) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < iters; ++i) launch_conv_igemm(p, tile, st);
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e0, e1);
+        *ms = t / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess) return fail(CCVPE_EHIP, "conv launch failed: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(CCVPE_EHIP, "conv execution failed: %s", hipGetErrorString(e2));
     return 0;
 }
 

@@ -87,6 +87,7 @@ struct SeParams {
     const float* w2;           // [C][SQ]
     const float* b2;           // [C]
     float* gate;               // [B][C] sigmoid(...)
+    float* pooled;             // [B][C] scratch: pooled means
 };
 void launch_se(const SeParams& p, hipStream_t s);
 

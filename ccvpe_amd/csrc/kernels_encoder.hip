@@ -166,18 +166,30 @@ void launch_depthwise(const DwParams& p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Squeeze-excite: pooled mean -> 1x1 (C->SQ) + swish -> 1x1 (SQ->C) + sigmoid.  One block per sample.
+// Squeeze-excite: (1) reduce the depthwise kernel's per-lane partial sums to the pooled mean, 64
+// channels per block with the S rows split over the block's 4 waves (coalesced 256 B rows);
+// (2) per sample: 1x1 (C->SQ) + swish -> 1x1 (SQ->C) + sigmoid.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void se_kernel(const SeParams p) {
+__global__ __launch_bounds__(256) void se_pool_kernel(const SeParams p, float* pooled) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y;
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float acc = 0.f;
+    if (c < p.C) {
+        const float* pp = p.pool_partial + (size_t)b * p.S * p.C + c;
+        for (int s = sl; s < p.S; s += 4) acc += pp[(size_t)s * p.C];
+    }
+    red[sl][cl] = acc;
+    __syncthreads();
+    if (sl == 0 && c < p.C) pooled[(size_t)b * p.C + c] = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) * p.inv_hw;
+}
+
+__global__ __launch_bounds__(256) void se_mlp_kernel(const SeParams p, const float* pooled_g) {
     __shared__ float pooled[1152];
     __shared__ float sq[64];
     const int b = blockIdx.x;
-    const float* pp = p.pool_partial + (size_t)b * p.S * p.C;
-    for (int c = threadIdx.x; c < p.C; c += 256) {
-        float acc = 0.f;
-        for (int s = 0; s < p.S; ++s) acc += pp[(size_t)s * p.C + c];
-        pooled[c] = acc * p.inv_hw;
-    }
+    for (int c = threadIdx.x; c < p.C; c += 256) pooled[c] = pooled_g[(size_t)b * p.C + c];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int j = wave; j < p.SQ; j += 4) {
@@ -196,7 +208,8 @@ __global__ __launch_bounds__(256) void se_kernel(const SeParams p) {
 }
 
 void launch_se(const SeParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(se_kernel, dim3(p.B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(se_pool_kernel, dim3((p.C + 63) / 64, p.B), dim3(256), 0, s, p, p.pooled);
+    hipLaunchKernelGGL(se_mlp_kernel, dim3(p.B), dim3(256), 0, s, p, (const float*)p.pooled);
 }
 
 // ------------------------------------------------------------------------------------------------

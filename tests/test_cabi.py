@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     text = open(os.path.join(ROOT, "include", "ccvpe.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ccvpe_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(ccvpe_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_builds_and_exports_header_symbols(built_library):

@@ -103,7 +103,9 @@ def test_full_tensor_against_oracle_oxford():
         if i == 2:
             continue
         err = (a - b.cpu()).abs().max().item() / a.abs().max().item()
-        assert err <= RTOL, f"{gu.OUTPUT_NAMES[i]}: {err:.3g}"
+        # full tensors include the worst-conditioned cosine scores (near-cancelling 224-term dot products);
+        # hold them to half the 1e-3 contract rather than the lattice's 1e-4
+        assert err <= 5 * RTOL, f"{gu.OUTPUT_NAMES[i]}: {err:.3g}"
 
 
 def test_batch32_properties_and_micro_batching():
