@@ -430,9 +430,11 @@ static ConvParams conv_params(const PackedConv& pc, const float* in, int in_ld, 
     ConvParams p{};
     p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = pc.cinp; p.OH = OH; p.OW = OW;
     p.KH = pc.KH; p.KW = pc.KW; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
-    p.wpk = pc.w; p.Kpad = pc.Kpad; p.nchunks = pc.nchunks; p.bias = pc.bias; p.N = pc.N; p.act = act;
+    p.wpk = pc.w; p.Kpad = pc.Kpad; p.Npad = round_up(pc.N, conv_igemm_npad()); p.nchunks = pc.nchunks; p.bias = pc.bias; p.N = pc.N; p.act = act;
     p.gate = nullptr; p.resid = nullptr; p.resid_ld = 0; p.ndst = 0; p.mode = MODE_CONV; p.deconv_cout = 0;
     p.M = B * OH * OW;
+    p.in_bytes = (unsigned)((size_t)B * H * W * in_ld * sizeof(float));
+    p.gate_bytes = (unsigned)((size_t)B * pc.cinp * sizeof(float));
     return p;
 }
 

@@ -30,6 +30,7 @@ struct ConvParams {
     int KH, KW, stride, pad_t, pad_l;
     const float* wpk;          // [Npad][Kpad], k contiguous
     int Kpad;                  // multiple of 32
+    int Npad;                  // rows in wpk (multiple of conv_igemm_npad())
     int nchunks;               // KH*KW*Cin/8 valid 8-channel chunks
     const float* bias;         // [N]
     int N;
@@ -42,10 +43,15 @@ struct ConvParams {
     int mode;
     int deconv_cout;
     int M;                     // B*OH*OW
+    unsigned in_bytes;         // extent of `in` for the bounds-checked buffer loads (< 2 GiB)
+    unsigned gate_bytes;
+    int div_cin8_mul;          // filled by launch_conv_igemm: chunk / (Cin/8) == (chunk * mul) >> 20
+    int div_kw_mul;            //                              tap / KW       == (tap * mul) >> 5
 };
 
 // tile = 0 picks automatically from (M, N); otherwise one of the TILE_* ids.
-enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_128x32 = 4 };
+enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_128x32 = 4,
+       TILE_256x16 = 5, TILE_128x48 = 6, TILE_128x80 = 7, TILE_256x32 = 8, TILE_COUNT = 9 };
 void launch_conv_igemm(const ConvParams& p, int tile, hipStream_t s);
 int conv_igemm_npad();       // row padding of packed weights (multiple every tile divides)
 int conv_igemm_last_tile();  // tile id of the most recent launch on this thread (then reset to 0)

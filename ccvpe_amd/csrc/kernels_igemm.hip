@@ -8,17 +8,21 @@
 //
 // Design (MI355X):  one workgroup = 4 wave64 = BM x BN output tile, K walked in 32-deep tiles that
 // are 4 "chunks" of 8 input channels of one filter tap, gathered straight from the NHWC activation
-// (no im2col buffer) with zero fill for the halo.  Tiles are register-staged (global_load_dwordx4 ->
-// ds_write_b128) into a double-buffered LDS image with 144-byte rows (conflict-free ds_read_b128), one
-// barrier per K tile, next tile's loads in flight under the current tile's MFMAs.
-// v_mfma_f32_32x32x2_f32 is exact fp32 (bitwise an fmaf chain) at 64 FLOP/clk/SIMD.  One ds_read_b128
-// per operand feeds four MFMAs: lane l holds k = 4*(l>>5)+j of its row for j = 0..3, the same k
-// permutation on A and B, so the contraction is complete after 4 issues.
+// (no im2col buffer).  The halo / ragged rows are handled without branches: activations are read with
+// raw buffer loads whose out-of-range offsets return zero.  Tiles are register-staged
+// (buffer_load_dwordx4 -> ds_write_b128) into a double-buffered LDS image with 144-byte rows
+// (conflict-free ds_read_b128), one barrier per K tile, the next tile's loads in flight under the
+// current tile's MFMAs.  v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 are exact fp32 (bitwise an
+// fmaf chain) at 64 FLOP/clk/SIMD; the 16x16 form serves narrow outputs (N = 16, 40, 80 ...) where a
+// 32-wide tile would waste matrix-core cycles on padding.  One ds_read_b128 per operand feeds four
+// MFMAs: lane l holds k = 4*(l / MT) + j of its row for j = 0..3, the same k permutation on A and B.
 #include "kernels.h"
 
 namespace ccvpe {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int BK = 32;
 static constexpr int LDK = 36;  // floats per LDS row: 32 + 4 pad -> 144 B, (144/16)=9 odd => b128 reads conflict-free
@@ -29,14 +33,32 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int MT> struct Mfma;
+template <> struct Mfma<32> {
+    using acc_t = f32x16;
+    static constexpr int NACC = 16;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+};
+template <> struct Mfma<16> {
+    using acc_t = f32x4;
+    static constexpr int NACC = 4;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int r, int lane) { return (lane >> 4) * 4 + r; }
+};
+
+template <int BM, int BN, int WGM, int WGN, int MT, bool GATE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     constexpr int WM = BM / WGM, WN = BN / WGN;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
-    constexpr int AR = BM / 32;  // float4 rows each thread stages for A
-    constexpr int BR = BN / 32;
+    constexpr int TM = WM / MT, TN = WN / MT;
+    static_assert(TM >= 1 && TN >= 1 && TM * MT * WGM == BM && TN * MT * WGN == BN, "tile must be whole MFMA tiles");
+    constexpr int AR = BM / 32;          // float4 rows each thread stages for A
+    constexpr int BR = (BN + 31) / 32;   // ... for B (last one partially used when BN % 32 != 0)
+    constexpr int KSTEP = 64 / MT * 4;   // k covered by one ds_read_b128 across the wave: 8 (MT 32) or 16 (MT 16)
+    constexpr int NKK = BK / KSTEP;
+    using M = Mfma<MT>;
+    using acc_t = typename M::acc_t;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][BM][LDK]
@@ -51,125 +73,135 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int kq = tid & 7;    // float4 slot inside the 32-deep K tile
     const int r0 = tid >> 3;   // 0..31
 
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gate_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE ? p.gate : p.in), 0, GATE ? p.gate_bytes : 0, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;   // beyond any tensor (< 2 GiB): the buffer load returns zeros
+
     // ---- per-row gather state (rows r0 + 32*j of the A tile) ----
     int a_base[AR], a_iy[AR], a_ix[AR], a_gb[AR];
     const int ohw = p.OH * p.OW;
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
-        int m = m0 + r0 + 32 * j;
-        bool ok = m < p.M;
-        int mm = ok ? m : 0;
-        int b = mm / ohw;
-        int rem = mm - b * ohw;
-        int oy = rem / p.OW;
-        int ox = rem - oy * p.OW;
-        int iy0 = oy * p.stride - p.pad_t;
-        int ix0 = ox * p.stride - p.pad_l;
-        a_base[j] = ((b * p.H + iy0) * p.W + ix0) * p.in_ld;
+        const int m = m0 + r0 + 32 * j;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / ohw;
+        const int rem = mm - b * ohw;
+        const int oy = rem / p.OW;
+        const int ox = rem - oy * p.OW;
+        const int iy0 = oy * p.stride - p.pad_t;
+        const int ix0 = ox * p.stride - p.pad_l;
+        a_base[j] = (((b * p.H + iy0) * p.W + ix0) * p.in_ld + (kq & 1) * 4) * 4;   // bytes
         a_iy[j] = ok ? iy0 : -(1 << 28);
         a_ix[j] = ix0;
-        a_gb[j] = b * p.Cin;
+        a_gb[j] = (b * p.Cin + (kq & 1) * 4) * 4;
     }
-    // chunk walk state: chunk g = kt*4 + (kq>>1) -> (tap = g / cin8, cc = g % cin8)
     const int cin8 = p.Cin >> 3;
-    const int c4 = (kq & 1) * 4;
-    int g = kq >> 1;
-    int tap = g / cin8;
-    int cc = g - tap * cin8;
-    int ky = tap / p.KW;
-    int kx = tap - ky * p.KW;
-
     const float* wrow[BR];
 #pragma unroll
-    for (int j = 0; j < BR; ++j) wrow[j] = p.wpk + (size_t)(n0 + r0 + 32 * j) * p.Kpad + kq * 4;
+    for (int j = 0; j < BR; ++j) wrow[j] = p.wpk + (size_t)min(n0 + r0 + 32 * j, p.Npad - 1) * p.Kpad + kq * 4;
 
-    float4 ra[AR], rb[BR];
+    f32x4 ra[AR], rb[BR];          // plain LLVM vectors (HIP's float4 struct arrays ended up in scratch)
+    f32x4 rg[GATE ? AR : 1];
 
-    auto load_tile = [&](int kt) {
-        const bool gok = g < p.nchunks;
-        const int koff = (ky * p.W + kx) * p.in_ld + cc * 8 + c4;
-#pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            int iy = a_iy[j] + ky, ix = a_ix[j] + kx;
-            bool ok = gok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(p.in + (a_base[j] + koff));
-                if (p.gate) {
-                    float4 gv = *reinterpret_cast<const float4*>(p.gate + a_gb[j] + cc * 8 + c4);
-                    v.x *= gv.x; v.y *= gv.y; v.z *= gv.z; v.w *= gv.w;
-                }
-            }
-            ra[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < BR; ++j) rb[j] = *reinterpret_cast<const float4*>(wrow[j] + kt * BK);
-        // advance the chunk walk by one K tile (4 chunks)
-        g += 4;
-        cc += 4;
-        while (cc >= cin8) {
-            cc -= cin8;
-            if (++kx == p.KW) { kx = 0; ++ky; }
-        }
-    };
-    auto store_tile = [&](int stage) {
-        float* as = As + stage * BM * LDK;
-        float* bs = Bs + stage * BN * LDK;
-#pragma unroll
-        for (int j = 0; j < AR; ++j) *reinterpret_cast<float4*>(as + (r0 + 32 * j) * LDK + kq * 4) = ra[j];
-#pragma unroll
-        for (int j = 0; j < BR; ++j) *reinterpret_cast<float4*>(bs + (r0 + 32 * j) * LDK + kq * 4) = rb[j];
-    };
+#define CCVPE_LOAD_TILE(kt)                                                                              \
+    {                                                                                                    \
+        const int g = (kt) * 4 + (kq >> 1);                                                              \
+        const int tap = (int)(((unsigned)g * (unsigned)p.div_cin8_mul) >> 20);                           \
+        const int cc = g - tap * cin8;                                                                   \
+        const int ky = (tap * p.div_kw_mul) >> 5;                                                        \
+        const int kx = tap - ky * p.KW;                                                                  \
+        const bool gok = g < p.nchunks;                                                                  \
+        const int koff = ((ky * p.W + kx) * p.in_ld + cc * 8) * 4;                                       \
+        _Pragma("unroll") for (int j = 0; j < AR; ++j) {                                                 \
+            const int iy = a_iy[j] + ky, ix = a_ix[j] + kx;                                              \
+            const bool ok = gok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);       \
+            const unsigned off = ok ? (unsigned)(a_base[j] + koff) : OOB;                                \
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0)); \
+            if (GATE) {                                                                                  \
+                rg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gate_rsrc, ok ? (unsigned)(a_gb[j] + cc * 32) : OOB, 0, 0)); \
+            }                                                                                            \
+        }                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < BR; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (kt) * BK); \
+    }
+#define CCVPE_STORE_TILE(stage)                                                                          \
+    {                                                                                                    \
+        float* as_ = As + (stage) * BM * LDK;                                                            \
+        float* bs_ = Bs + (stage) * BN * LDK;                                                            \
+        _Pragma("unroll") for (int j = 0; j < AR; ++j) {                                                 \
+            f32x4 v_ = ra[j];                                                                            \
+            if (GATE) v_ *= rg[j];                                                                       \
+            *reinterpret_cast<f32x4*>(as_ + (r0 + 32 * j) * LDK + kq * 4) = v_;                          \
+        }                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < BR; ++j)                                                   \
+            if (BN % 32 == 0 || r0 + 32 * j < BN) *reinterpret_cast<f32x4*>(bs_ + (r0 + 32 * j) * LDK + kq * 4) = rb[j]; \
+    }
 
-    f32x16 acc[TM][TN];
+    acc_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < M::NACC; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = p.Kpad / BK;
-    load_tile(0);
-    store_tile(0);
+    CCVPE_LOAD_TILE(0);
+    CCVPE_STORE_TILE(0);
     __syncthreads();
 
-    const int a_row = wm * WM + (lane & 31);
-    const int b_row = wn * WN + (lane & 31);
-    const int k_lane = (lane >> 5) * 4;
+    const int a_row = wm * WM + (lane % MT);
+    const int b_row = wn * WN + (lane % MT);
+    const int k_lane = (lane / MT) * 4;
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int stage = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        // unconditional prefetch: the last iteration re-reads its own tile into the idle stage, which keeps
+        // the loop free of branches (and the staging registers out of scratch)
+        const int ktn = min(kt + 1, nkt - 1);
+        CCVPE_LOAD_TILE(ktn);
+        // keep the prefetch ABOVE the MFMA block: without this fence hipcc sinks the loads to just before
+        // the ds_writes (to shorten register live ranges) and every K tile eats a full memory latency
+        __builtin_amdgcn_sched_barrier(0);
         const float* as = As + stage * BM * LDK + a_row * LDK + k_lane;
         const float* bs = Bs + stage * BN * LDK + b_row * LDK + k_lane;
+        // fragments double-buffered in registers: kk+1's ds_reads are in flight under kk's MFMAs
+        f32x4 a[2][TM], b[2][TN];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float4 a[TM], b[TN];
+        for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(as + i * MT * LDK);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDK + kk * 8);
+        for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(bs + j * MT * LDK);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(bs + j * 32 * LDK + kk * 8);
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < NKK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nxt][i] = *reinterpret_cast<const f32x4*>(as + i * MT * LDK + (kk + 1) * KSTEP);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nxt][j] = *reinterpret_cast<const f32x4*>(bs + j * MT * LDK + (kk + 1) * KSTEP);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = M::run(a[cur][i].x, b[cur][j].x, acc[i][j]);
+                    acc[i][j] = M::run(a[cur][i].y, b[cur][j].y, acc[i][j]);
+                    acc[i][j] = M::run(a[cur][i].z, b[cur][j].z, acc[i][j]);
+                    acc[i][j] = M::run(a[cur][i].w, b[cur][j].w, acc[i][j]);
                 }
         }
-        if (kt + 1 < nkt) store_tile(stage ^ 1);
+        CCVPE_STORE_TILE(stage ^ 1);
         __syncthreads();
     }
+#undef CCVPE_LOAD_TILE
+#undef CCVPE_STORE_TILE
 
-    // ---- epilogue: C/D layout col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m) ----
-    const int col = lane & 31;
-    const int rhalf = (lane >> 5) * 4;
+    // ---- epilogue: column n on the lane, rows m in the accumulator registers ----
+    const int col = lane % MT;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + col;
+        const int n = n0 + wn * WN + j * MT + col;
         const bool nok = n < p.N;
         const float bias = nok ? p.bias[n] : 0.f;
         int q = 0, o = n;
@@ -181,16 +213,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+            for (int r = 0; r < M::NACC; ++r) {
+                const int m = m0 + wm * WM + i * MT + M::row(r, lane);
                 if (!nok || m >= p.M) continue;
                 float v = apply_act(acc[i][j][r] + bias, p.act);
                 int opix = m;
                 if (p.mode == MODE_DECONV) {
-                    int x = m % p.W;
-                    int t = m / p.W;
-                    int y = t % p.H;
-                    int b = t / p.H;
+                    const int x = m % p.W;
+                    const int t = m / p.W;
+                    const int y = t % p.H;
+                    const int b = t / p.H;
                     opix = (b * 2 * p.H + 2 * y + dy) * (2 * p.W) + 2 * x + dx;
                 } else if (p.resid) {
                     v += p.resid[(size_t)m * p.resid_ld + n];
@@ -203,11 +235,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN>
-static void launch_cfg(const ConvParams& p, hipStream_t s) {
+struct TileCfg { int id, bm, bn; double intrinsic; const char* name; };
+static const TileCfg TILES[] = {
+    {TILE_128x128, 128, 128, 1.00, "conv_igemm_128x128"},
+    {TILE_128x64, 128, 64, 0.95, "conv_igemm_128x64"},
+    {TILE_64x64, 64, 64, 0.85, "conv_igemm_64x64"},
+    {TILE_128x32, 128, 32, 0.85, "conv_igemm_128x32"},
+    {TILE_256x16, 256, 16, 0.80, "conv_igemm_256x16_m16"},
+    {TILE_128x48, 128, 48, 0.85, "conv_igemm_128x48_m16"},
+    {TILE_128x80, 128, 80, 0.90, "conv_igemm_128x80_m16"},
+    {TILE_256x32, 256, 32, 0.90, "conv_igemm_256x32"},
+};
+
+template <int BM, int BN, int WGM, int WGN, int MT, bool GATE>
+static void launch_cfg2(const ConvParams& p, hipStream_t s) {
     constexpr size_t lds = 2 * (BM + BN) * LDK * sizeof(float);
     static bool attr_done = false;
-    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN>;
+    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, MT, GATE>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
@@ -216,18 +260,19 @@ static void launch_cfg(const ConvParams& p, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
 }
 
+template <int BM, int BN, int WGM, int WGN, int MT>
+static void launch_cfg(const ConvParams& p, hipStream_t s) {
+    if (p.gate) launch_cfg2<BM, BN, WGM, WGN, MT, true>(p, s);
+    else launch_cfg2<BM, BN, WGM, WGN, MT, false>(p, s);
+}
+
 int conv_igemm_npad() { return 128; }
 
 static int pick_tile(const ConvParams& p) {
-    struct Cand { int id, bm, bn; double intrinsic; };
-    static const Cand cands[] = {
-        {TILE_128x128, 128, 128, 1.00}, {TILE_128x64, 128, 64, 0.95}, {TILE_64x64, 64, 64, 0.85},
-        {TILE_128x32, 128, 32, 0.85},
-    };
     const double cus = 256.0;
     int best = TILE_64x64;
     double best_score = -1.0;
-    for (const Cand& c : cands) {
+    for (const TileCfg& c : TILES) {
         double gm = (p.M + c.bm - 1) / c.bm, gn = (p.N + c.bn - 1) / c.bn;
         double blocks = gm * gn;
         double util = ((double)p.M * p.N) / (gm * c.bm * gn * c.bn);
@@ -242,24 +287,51 @@ static int pick_tile(const ConvParams& p) {
 static thread_local int g_last_tile = 0;
 int conv_igemm_last_tile() { int t = g_last_tile; g_last_tile = 0; return t; }
 const char* conv_igemm_tile_name(int tile) {
-    switch (tile) {
-        case TILE_128x128: return "conv_igemm_128x128";
-        case TILE_128x64: return "conv_igemm_128x64";
-        case TILE_64x64: return "conv_igemm_64x64";
-        case TILE_128x32: return "conv_igemm_128x32";
-        default: return "";
-    }
+    for (const TileCfg& c : TILES) if (c.id == tile) return c.name;
+    return "";
 }
 
-void launch_conv_igemm(const ConvParams& p, int tile, hipStream_t s) {
+// exact small-range division by multiplication: q = (g * mul) >> 20 for 0 <= g < limit
+static int find_div_mul(int d, int limit) {
+    const unsigned mul = ((1u << 20) + d - 1) / d;
+    for (int g = 0; g < limit; ++g)
+        if ((int)(((unsigned)g * mul) >> 20) != g / d) return -1;
+    return (int)mul;
+}
+
+int conv_igemm_prepare(ConvParams& p) {
+    const int cin8 = p.Cin / 8;
+    const int limit = p.Kpad / 8 + 8;
+    const int mul = find_div_mul(cin8, limit);
+    if (mul < 0 || (long long)limit * mul >= (1LL << 32)) return -1;
+    p.div_cin8_mul = mul;
+    // tap / KW for tap < 16: (tap * m) >> 5
+    int kwm = -1;
+    for (int m = 1; m < 64 && kwm < 0; ++m) {
+        bool ok = true;
+        for (int t = 0; t < 16 && ok; ++t) ok = ((t * m) >> 5) == t / p.KW;
+        if (ok) kwm = m;
+    }
+    if (kwm < 0) return -1;
+    p.div_kw_mul = kwm;
+    return 0;
+}
+
+void launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
+    ConvParams p = p_in;
+    if (conv_igemm_prepare(p) != 0) return;   // geometry outside the supported range: validated at plan time
     if (tile == TILE_AUTO) tile = pick_tile(p);
     g_last_tile = tile;
     switch (tile) {
-        case TILE_128x128: launch_cfg<128, 128, 2, 2>(p, s); break;
-        case TILE_128x64:  launch_cfg<128, 64, 2, 2>(p, s); break;
-        case TILE_128x32:  launch_cfg<128, 32, 4, 1>(p, s); break;
+        case TILE_128x128: launch_cfg<128, 128, 2, 2, 32>(p, s); break;
+        case TILE_128x64:  launch_cfg<128, 64, 2, 2, 32>(p, s); break;
+        case TILE_128x32:  launch_cfg<128, 32, 4, 1, 32>(p, s); break;
+        case TILE_256x32:  launch_cfg<256, 32, 4, 1, 32>(p, s); break;
+        case TILE_256x16:  launch_cfg<256, 16, 4, 1, 16>(p, s); break;
+        case TILE_128x48:  launch_cfg<128, 48, 4, 1, 16>(p, s); break;
+        case TILE_128x80:  launch_cfg<128, 80, 4, 1, 16>(p, s); break;
         case TILE_64x64:
-        default:           launch_cfg<64, 64, 2, 2>(p, s); break;
+        default:           launch_cfg<64, 64, 2, 2, 32>(p, s); break;
     }
 }
 

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from ccvpe_amd import _lib
 
-TILES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32"}
+TILES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x16m", 6: "128x48m", 7: "128x80m", 8: "256x32"}
 for k, v in list(getattr(_lib, "EXTRA_TILES", {}).items()):
     TILES[k] = v
 
