@@ -47,6 +47,8 @@ SYMBOLS = [
                                         C.POINTER(Outputs), C.c_void_p]),
     ("ccvpe_profile_row", C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_float),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("ccvpe_op_num_tiles", C.c_int, []),
+    ("ccvpe_op_tile_name", C.c_char_p, [C.c_int32]),
     ("ccvpe_op_conv2d", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_void_p]),

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -149,6 +150,9 @@ struct Op {
     std::function<void(const Ctx&)> fn;
     std::vector<int> uses;
     double flops = 0, bytes = 0;
+    // implicit-GEMM launches: tile id the launch uses (0 = heuristic) - set by Plan::autotune
+    std::shared_ptr<int> tile;
+    int gemm_m = 0, gemm_n = 0;
 };
 
 struct TapInfo { Tensor t; int coff; int C; };
@@ -172,6 +176,14 @@ struct Plan {
         Op o; o.name = name; o.fn = std::move(fn); o.flops = flops; o.bytes = bytes;
         for (auto& t : uses) o.uses.push_back(t.id);
         ops.push_back(std::move(o));
+    }
+    void add_conv(const std::string& name, std::vector<Tensor> uses, int gemm_m, int gemm_n,
+                  std::function<void(const Ctx&, int)> fn, double flops, double bytes) {
+        auto tp = std::make_shared<int>(TILE_AUTO);
+        add(name, std::move(uses), [fn, tp](const Ctx& c) { fn(c, *tp); }, flops, bytes);
+        ops.back().tile = tp;
+        ops.back().gemm_m = gemm_m;
+        ops.back().gemm_n = gemm_n;
     }
     void assign() {
         const int n = (int)size.size();
@@ -214,6 +226,7 @@ struct ccvpe_handle_s {
     std::set<std::string> skipped;
     bool finalized = false;
     bool debug = false;
+    bool autotune = true;
     std::vector<void*> dev_allocs;
     EncoderW grd_enc, sat_enc;
     PackedConv grd_heads, sat_desc;
@@ -357,7 +370,13 @@ static int build_encoder(ccvpe_handle_s* h, EncoderW& e, const std::string& p) {
         bw.sq = se_squeeze(b.cin);
         if ((rc = upload(h, h->host[q + "._se_reduce.weight"], &bw.se_w1))) return rc;
         if ((rc = upload(h, h->host[q + "._se_reduce.bias"], &bw.se_b1))) return rc;
-        if ((rc = upload(h, h->host[q + "._se_expand.weight"], &bw.se_w2))) return rc;
+        {   // [C][SQ] -> [SQ][C] so the excite phase reads consecutive channels
+            const auto& w2 = h->host[q + "._se_expand.weight"];
+            std::vector<float> t((size_t)mid * bw.sq);
+            for (int c = 0; c < mid; ++c)
+                for (int j = 0; j < bw.sq; ++j) t[(size_t)j * mid + c] = w2[(size_t)c * bw.sq + j];
+            if ((rc = upload(h, t, &bw.se_w2))) return rc;
+        }
         if ((rc = upload(h, h->host[q + "._se_expand.bias"], &bw.se_b2))) return rc;
         if ((rc = pack_pointwise_bn(h, bw.project, q + "._project_conv.weight", q + "._bn2", b.cout, mid))) return rc;
     }
@@ -470,10 +489,10 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
             e = pl.alloc(B, ch, cw, mid);
             const PackedConv* pc = &bw.expand;
             const int hh = ch, ww = cw;
-            pl.add(bn + ".expand", {xin, e}, [=](const Ctx& c) {
+            pl.add_conv(bn + ".expand", {xin, e}, B * hh * ww, pc->N, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(xin), xin.C, B, hh, ww, hh, ww, 1, 0, 0, ACT_SWISH);
                 p.dst[0] = {c.ptr(e), mid, 0}; p.ndst = 1;
-                launch_conv_igemm(p, TILE_AUTO, c.stream);
+                launch_conv_igemm(p, tile, c.stream);
             }, 2.0 * B * ch * cw * b.cin * mid, 4.0 * B * ch * cw * (b.cin + mid));
         }
         static_pad(b.k, b.s, lo, hi);
@@ -510,13 +529,13 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
             std::vector<Tensor> uses = {d, gate, o};
             if (skip) uses.push_back(xin);
             for (int t = 0; t < td.n; ++t) uses.push_back(td.t[t]);
-            pl.add(bn + ".project", uses, [=](const Ctx& c) {
+            pl.add_conv(bn + ".project", uses, B * oh * ow, pc->N, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(d), mid, B, oh, ow, oh, ow, 1, 0, 0, ACT_NONE);
                 p.gate = c.ptr(gate);
                 if (skip) { p.resid = c.ptr(xin); p.resid_ld = xin.C; }
                 p.dst[0] = {c.ptr(o), o.C, 0}; p.ndst = 1;
                 for (int t = 0; t < td.n; ++t) p.dst[p.ndst++] = {c.ptr(td.t[t]), td.t[t].C, td.coff[t]};
-                launch_conv_igemm(p, TILE_AUTO, c.stream);
+                launch_conv_igemm(p, tile, c.stream);
             }, 2.0 * B * oh * ow * mid * b.cout, 4.0 * B * oh * ow * (mid + b.cout * (1 + td.n)));
         }
         out.tap[i] = o;
@@ -528,10 +547,10 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         const PackedConv* pc = &ew.head;
         Tensor x = cur;
         const int hh = ch, ww = cw;
-        pl.add(tag + ".head", {x, vol}, [=](const Ctx& c) {
+        pl.add_conv(tag + ".head", {x, vol}, B * hh * ww, pc->N, [=](const Ctx& c, int tile) {
             ConvParams p = conv_params(*pc, c.ptr(x), x.C, B, hh, ww, hh, ww, 1, 0, 0, ACT_SWISH);
             p.dst[0] = {c.ptr(vol), 1280, 0}; p.ndst = 1;
-            launch_conv_igemm(p, TILE_AUTO, c.stream);
+            launch_conv_igemm(p, tile, c.stream);
         }, 2.0 * B * ch * cw * 320 * 1280, 4.0 * B * ch * cw * 1600);
     }
     out.vol = vol;
@@ -587,10 +606,10 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
     {
         const PackedConv* pc = &h->grd_heads;
         Tensor x = genc.vol;
-        pl.add("grd.heads", {x, ghead}, [=](const Ctx& c) {
+        pl.add_conv("grd.heads", {x, ghead}, B * fh * fw, pc->N, [=](const Ctx& c, int tile) {
             ConvParams p = conv_params(*pc, c.ptr(x), 1280, B, fh, fw, fh, fw, 1, 0, 0, ACT_NONE);
             p.dst[0] = {c.ptr(ghead), ntot, 0}; p.ndst = 1;
-            launch_conv_igemm(p, TILE_AUTO, c.stream);
+            launch_conv_igemm(p, tile, c.stream);
         }, 2.0 * B * fh * fw * 1280 * ntot, 4.0 * B * fh * fw * (1280 + ntot));
         GrdDescParams gp{};
         gp.B = B; gp.Hf = fh; gp.Wf = fw; gp.Ntot = ntot; gp.nlev = 6; gp.Ltot = ltot;
@@ -607,10 +626,10 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
     {
         const PackedConv* pc = &h->sat_desc;
         Tensor x = senc.vol;
-        pl.add("sat.descmap", {x, dmap}, [=](const Ctx& c) {
+        pl.add_conv("sat.descmap", {x, dmap}, B * 8 * 8, pc->N, [=](const Ctx& c, int tile) {
             ConvParams p = conv_params(*pc, c.ptr(x), 1280, B, 16, 16, 8, 8, 2, 0, 0, ACT_NONE);
             p.dst[0] = {c.ptr(dmap), D, 0}; p.ndst = 1;
-            launch_conv_igemm(p, TILE_AUTO, c.stream);
+            launch_conv_igemm(p, tile, c.stream);
         }, 2.0 * B * 64 * 5120.0 * D, 4.0 * (B * 256 * 1280.0 + 5120.0 * D));
         pl.taps["sat_descriptor_map"] = {dmap, 0, D};
     }
@@ -622,30 +641,30 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
         {
             const PackedConv* pc = &dw.deconv[j];
             const int cout = l.dout;
-            pl.add(tag + ".deconv", {din, cat}, [=](const Ctx& c) {
+            pl.add_conv(tag + ".deconv", {din, cat}, B * hin * hin, pc->N, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(din), din.C, B, hin, hin, hin, hin, 1, 0, 0, ACT_NONE);
                 p.mode = MODE_DECONV; p.deconv_cout = cout;
                 p.dst[0] = {c.ptr(cat), cat.C, 0}; p.ndst = 1;
-                launch_conv_igemm(p, TILE_AUTO, c.stream);
+                launch_conv_igemm(p, tile, c.stream);
             }, 2.0 * B * hin * hin * (double)l.din * 4 * l.dout, 4.0 * B * hin * hin * ((double)din.C + 4.0 * l.dout));
         }
         Tensor mid = pl.alloc(B, hout, hout, l.mid);
         {
             const PackedConv* pc = &dw.conva[j];
-            pl.add(tag + ".conv_a", {cat, mid}, [=](const Ctx& c) {
+            pl.add_conv(tag + ".conv_a", {cat, mid}, B * hout * hout, pc->N, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(cat), cat.C, B, hout, hout, hout, hout, 1, 1, 1, ACT_RELU);
                 p.dst[0] = {c.ptr(mid), mid.C, 0}; p.ndst = 1;
-                launch_conv_igemm(p, TILE_AUTO, c.stream);
+                launch_conv_igemm(p, tile, c.stream);
             }, 2.0 * B * hout * hout * 9.0 * cat.C * l.mid, 4.0 * B * hout * hout * ((double)cat.C + l.mid));
         }
         if (j == 5) return mid;   // tail conv handled by the caller
         Tensor o = pl.alloc(B, hout, hout, l.out);
         {
             const PackedConv* pc = &dw.convb[j];
-            pl.add(tag + ".conv_b", {mid, o}, [=](const Ctx& c) {
+            pl.add_conv(tag + ".conv_b", {mid, o}, B * hout * hout, pc->N, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(mid), mid.C, B, hout, hout, hout, hout, 1, 1, 1, ACT_NONE);
                 p.dst[0] = {c.ptr(o), o.C, 0}; p.ndst = 1;
-                launch_conv_igemm(p, TILE_AUTO, c.stream);
+                launch_conv_igemm(p, tile, c.stream);
             }, 2.0 * B * hout * hout * 9.0 * l.mid * l.out, 4.0 * B * hout * hout * ((double)l.mid + l.out));
         }
         return o;
@@ -765,6 +784,7 @@ int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
     h->cfg = *cfg;
     if (h->cfg.micro_batch <= 0) h->cfg.micro_batch = 32;
     h->vs = make_variant(cfg->variant);
+    if (const char* e = getenv("CCVPE_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
     const int n = (int)(cfg->ori_noise / 18.f);
     for (int k = 0; k < 6; ++k)
         h->rolls[k] = (cfg->variant == CCVPE_VARIANT_VIGOR_ORI_PRIOR && k > 0) ? 2 * n + 1 : h->vs.n_rolls;
@@ -864,6 +884,45 @@ int ccvpe_output_channels(ccvpe_handle h, int32_t level) {
     return h->rolls[level];
 }
 
+// Per-layer tile selection by measurement: every implicit-GEMM launch of the plan is timed with each
+// candidate tile (hipEvents, on the plan's own buffers - timing does not depend on the data) and the
+// fastest is kept.  Runs once per (batch, ground size) plan, before its first forward.
+static int autotune_plan(ccvpe_handle h, Plan& pl) {
+    Ctx c;
+    c.arena = h->arena; c.off = &pl.off; c.stream = nullptr;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipMemset(h->arena, 0, pl.total * sizeof(float)));
+    const int nt = conv_igemm_num_tiles();
+    for (auto& op : pl.ops) {
+        if (!op.tile) continue;
+        ConvParams q{};
+        q.M = op.gemm_m; q.N = op.gemm_n;
+        int best = 0;
+        float best_ms = 1e30f;
+        for (int t = 1; t <= nt; ++t) {
+            if (conv_igemm_tile_util(q, t) < 0.45) continue;
+            *op.tile = t;
+            op.fn(c);   // warm-up (also sets the dynamic-LDS attribute on first use)
+            HIPCHK(hipEventRecord(e0, nullptr));
+            op.fn(c);
+            op.fn(c);
+            HIPCHK(hipEventRecord(e1, nullptr));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best_ms) { best_ms = ms; best = t; }
+        }
+        *op.tile = best;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CCVPE_EHIP, "autotune launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 static int get_plan(ccvpe_handle h, int B, int gh, int gw, Plan** out) {
     for (auto& p : h->plans)
         if (p->B == B && p->gh == gh && p->gw == gw && p->debug == h->debug) { *out = p.get(); return 0; }
@@ -880,6 +939,10 @@ static int get_plan(ccvpe_handle h, int B, int gh, int gw, Plan** out) {
         if (e != hipSuccess) { h->arena_floats = 0; return fail(CCVPE_ENOMEM, "workspace of %zu bytes: %s", pl->total * sizeof(float), hipGetErrorString(e)); }
         h->arena = (float*)d;
         h->arena_floats = pl->total;
+    }
+    if (h->autotune) {
+        int rc2 = autotune_plan(h, *pl);
+        if (rc2) return rc2;
     }
     *out = pl.get();
     h->plans.push_back(std::move(pl));
@@ -1028,6 +1091,9 @@ int ccvpe_read_tap(ccvpe_handle h, const char* name, float* host_dst, size_t cap
     if (shape_out) { shape_out[0] = t.B; shape_out[1] = ti.C; shape_out[2] = t.H; shape_out[3] = t.W; }
     return 0;
 }
+
+int ccvpe_op_num_tiles(void) { return conv_igemm_num_tiles(); }
+const char* ccvpe_op_tile_name(int32_t tile) { return conv_igemm_tile_name(tile); }
 
 int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w, const float* bias,
                     int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t act, int32_t tile,

@@ -50,8 +50,10 @@ struct ConvParams {
 };
 
 // tile = 0 picks automatically from (M, N); otherwise one of the TILE_* ids.
-enum { TILE_AUTO = 0, TILE_128x128 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_128x32 = 4,
-       TILE_256x16 = 5, TILE_128x48 = 6, TILE_128x80 = 7, TILE_256x32 = 8, TILE_COUNT = 9 };
+enum { TILE_AUTO = 0 };      // tile ids are 1..conv_igemm_num_tiles()
+int conv_igemm_num_tiles();
+double conv_igemm_tile_util(const ConvParams& p, int tile);
+int conv_igemm_prepare(ConvParams& p);
 void launch_conv_igemm(const ConvParams& p, int tile, hipStream_t s);
 int conv_igemm_npad();       // row padding of packed weights (multiple every tile divides)
 int conv_igemm_last_tile();  // tile id of the most recent launch on this thread (then reset to 0)
@@ -90,7 +92,7 @@ struct SeParams {
     float inv_hw;
     const float* w1;           // [SQ][C]
     const float* b1;           // [SQ]
-    const float* w2;           // [C][SQ]
+    const float* w2;           // [SQ][C] (transposed at pack time)
     const float* b2;           // [C]
     float* gate;               // [B][C] sigmoid(...)
     float* pooled;             // [B][C] scratch: pooled means

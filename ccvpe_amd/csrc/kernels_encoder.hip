@@ -185,10 +185,12 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const SeParams p, float* p
     if (sl == 0 && c < p.C) pooled[(size_t)b * p.C + c] = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) * p.inv_hw;
 }
 
+// grid (ceil(C/256), B): every block recomputes the SQ squeezed values of its sample (C*SQ MACs, cheap)
+// and produces 256 gates; w2t is [SQ][C] so consecutive lanes read consecutive channels.
 __global__ __launch_bounds__(256) void se_mlp_kernel(const SeParams p, const float* pooled_g) {
     __shared__ float pooled[1152];
     __shared__ float sq[64];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     for (int c = threadIdx.x; c < p.C; c += 256) pooled[c] = pooled_g[(size_t)b * p.C + c];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -200,16 +202,17 @@ __global__ __launch_bounds__(256) void se_mlp_kernel(const SeParams p, const flo
         if (lane == 0) sq[j] = swishf(acc + p.b1[j]);
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < p.C; c += 256) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < p.C) {
         float acc = p.b2[c];
-        for (int j = 0; j < p.SQ; ++j) acc = fmaf(p.w2[c * p.SQ + j], sq[j], acc);
+        for (int j = 0; j < p.SQ; ++j) acc = fmaf(p.w2[(size_t)j * p.C + c], sq[j], acc);
         p.gate[(size_t)b * p.C + c] = 1.f / (1.f + __expf(-acc));
     }
 }
 
 void launch_se(const SeParams& p, hipStream_t s) {
     hipLaunchKernelGGL(se_pool_kernel, dim3((p.C + 63) / 64, p.B), dim3(256), 0, s, p, p.pooled);
-    hipLaunchKernelGGL(se_mlp_kernel, dim3(p.B), dim3(256), 0, s, p, (const float*)p.pooled);
+    hipLaunchKernelGGL(se_mlp_kernel, dim3((p.C + 255) / 256, p.B), dim3(256), 0, s, p, (const float*)p.pooled);
 }
 
 // ------------------------------------------------------------------------------------------------

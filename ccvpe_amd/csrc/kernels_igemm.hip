@@ -235,18 +235,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 }
 
-struct TileCfg { int id, bm, bn; double intrinsic; const char* name; };
-static const TileCfg TILES[] = {
-    {TILE_128x128, 128, 128, 1.00, "conv_igemm_128x128"},
-    {TILE_128x64, 128, 64, 0.95, "conv_igemm_128x64"},
-    {TILE_64x64, 64, 64, 0.85, "conv_igemm_64x64"},
-    {TILE_128x32, 128, 32, 0.85, "conv_igemm_128x32"},
-    {TILE_256x16, 256, 16, 0.80, "conv_igemm_256x16_m16"},
-    {TILE_128x48, 128, 48, 0.85, "conv_igemm_128x48_m16"},
-    {TILE_128x80, 128, 80, 0.90, "conv_igemm_128x80_m16"},
-    {TILE_256x32, 256, 32, 0.90, "conv_igemm_256x32"},
-};
-
 template <int BM, int BN, int WGM, int WGN, int MT, bool GATE>
 static void launch_cfg2(const ConvParams& p, hipStream_t s) {
     constexpr size_t lds = 2 * (BM + BN) * LDK * sizeof(float);
@@ -266,30 +254,62 @@ static void launch_cfg(const ConvParams& p, hipStream_t s) {
     else launch_cfg2<BM, BN, WGM, WGN, MT, false>(p, s);
 }
 
+// Tile table.  id = index + 1 (0 is TILE_AUTO).  `intrinsic` is only the prior used when the plan has not been
+// autotuned (ccvpe_api.hip times every candidate per layer on the device and keeps the fastest).
+struct TileCfg { int bm, bn; double intrinsic; const char* name; void (*launch)(const ConvParams&, hipStream_t); };
+static const TileCfg TILES[] = {
+    {128, 128, 0.95, "conv_igemm_128x128_m32", launch_cfg<128, 128, 2, 2, 32>},
+    {128, 64, 0.85, "conv_igemm_128x64_m32", launch_cfg<128, 64, 2, 2, 32>},
+    {64, 64, 0.85, "conv_igemm_64x64_m32", launch_cfg<64, 64, 2, 2, 32>},
+    {128, 32, 0.85, "conv_igemm_128x32_m32", launch_cfg<128, 32, 4, 1, 32>},
+    {256, 16, 0.60, "conv_igemm_256x16_m16", launch_cfg<256, 16, 4, 1, 16>},
+    {128, 48, 0.85, "conv_igemm_128x48_m16", launch_cfg<128, 48, 4, 1, 16>},
+    {128, 80, 1.00, "conv_igemm_128x80_m16", launch_cfg<128, 80, 4, 1, 16>},
+    {256, 32, 0.70, "conv_igemm_256x32_m32", launch_cfg<256, 32, 4, 1, 32>},
+    {128, 128, 1.00, "conv_igemm_128x128_m16", launch_cfg<128, 128, 2, 2, 16>},
+    {128, 64, 0.95, "conv_igemm_128x64_m16", launch_cfg<128, 64, 2, 2, 16>},
+    {128, 32, 0.85, "conv_igemm_128x32_m16", launch_cfg<128, 32, 4, 1, 16>},
+    {128, 16, 0.60, "conv_igemm_128x16_m16", launch_cfg<128, 16, 4, 1, 16>},
+    {128, 96, 1.00, "conv_igemm_128x96_m16", launch_cfg<128, 96, 4, 1, 16>},
+    {128, 112, 1.00, "conv_igemm_128x112_m16", launch_cfg<128, 112, 4, 1, 16>},
+    {64, 64, 0.85, "conv_igemm_64x64_m16", launch_cfg<64, 64, 2, 2, 16>},
+    {64, 32, 0.70, "conv_igemm_64x32_m16", launch_cfg<64, 32, 2, 2, 16>},
+    {256, 48, 0.85, "conv_igemm_256x48_m16", launch_cfg<256, 48, 4, 1, 16>},
+    {64, 128, 0.90, "conv_igemm_64x128_m16", launch_cfg<64, 128, 2, 2, 16>},
+};
+static constexpr int NTILES = (int)(sizeof(TILES) / sizeof(TILES[0]));
+
 int conv_igemm_npad() { return 128; }
+int conv_igemm_num_tiles() { return NTILES; }
+
+// fraction of the launched MFMA work that is useful (padding of M and N to the tile)
+double conv_igemm_tile_util(const ConvParams& p, int tile) {
+    if (tile < 1 || tile > NTILES) return 0.0;
+    const TileCfg& c = TILES[tile - 1];
+    double gm = (p.M + c.bm - 1) / c.bm, gn = (p.N + c.bn - 1) / c.bn;
+    return ((double)p.M * p.N) / (gm * c.bm * gn * c.bn);
+}
 
 static int pick_tile(const ConvParams& p) {
     const double cus = 256.0;
-    int best = TILE_64x64;
+    int best = 3;
     double best_score = -1.0;
-    for (const TileCfg& c : TILES) {
+    for (int t = 1; t <= NTILES; ++t) {
+        const TileCfg& c = TILES[t - 1];
         double gm = (p.M + c.bm - 1) / c.bm, gn = (p.N + c.bn - 1) / c.bn;
         double blocks = gm * gn;
-        double util = ((double)p.M * p.N) / (gm * c.bm * gn * c.bn);
+        double util = conv_igemm_tile_util(p, t);
         double rounds = (double)(long long)((blocks + cus - 1) / cus);
         double quant = blocks / (rounds * cus);
         double score = util * quant * c.intrinsic;
-        if (score > best_score) { best_score = score; best = c.id; }
+        if (score > best_score) { best_score = score; best = t; }
     }
     return best;
 }
 
 static thread_local int g_last_tile = 0;
 int conv_igemm_last_tile() { int t = g_last_tile; g_last_tile = 0; return t; }
-const char* conv_igemm_tile_name(int tile) {
-    for (const TileCfg& c : TILES) if (c.id == tile) return c.name;
-    return "";
-}
+const char* conv_igemm_tile_name(int tile) { return (tile >= 1 && tile <= NTILES) ? TILES[tile - 1].name : ""; }
 
 // exact small-range division by multiplication: q = (g * mul) >> 20 for 0 <= g < limit
 static int find_div_mul(int d, int limit) {
@@ -320,19 +340,9 @@ int conv_igemm_prepare(ConvParams& p) {
 void launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
     ConvParams p = p_in;
     if (conv_igemm_prepare(p) != 0) return;   // geometry outside the supported range: validated at plan time
-    if (tile == TILE_AUTO) tile = pick_tile(p);
+    if (tile < 1 || tile > NTILES) tile = pick_tile(p);
     g_last_tile = tile;
-    switch (tile) {
-        case TILE_128x128: launch_cfg<128, 128, 2, 2, 32>(p, s); break;
-        case TILE_128x64:  launch_cfg<128, 64, 2, 2, 32>(p, s); break;
-        case TILE_128x32:  launch_cfg<128, 32, 4, 1, 32>(p, s); break;
-        case TILE_256x32:  launch_cfg<256, 32, 4, 1, 32>(p, s); break;
-        case TILE_256x16:  launch_cfg<256, 16, 4, 1, 16>(p, s); break;
-        case TILE_128x48:  launch_cfg<128, 48, 4, 1, 16>(p, s); break;
-        case TILE_128x80:  launch_cfg<128, 80, 4, 1, 16>(p, s); break;
-        case TILE_64x64:
-        default:           launch_cfg<64, 64, 2, 2, 32>(p, s); break;
-    }
+    TILES[tile - 1].launch(p, s);
 }
 
 }  // namespace ccvpe

@@ -129,9 +129,11 @@ int ccvpe_profile_row(ccvpe_handle h, int32_t i, char* name_buf, size_t name_cap
  * convolution through the implicit-GEMM MFMA kernel.  in [B,H,W,Cin] (device, Cin % 8 == 0),
  * w [Cout,Cin,KH,KW] and bias [Cout] in the reference's layout (host or device; bias may be NULL),
  * symmetric zero padding `pad`, out [B,OH,OW,Cout] (device) with OH = (H + 2*pad - KH)/stride + 1.
- * act: 0 none, 1 relu, 2 swish.  tile: 0 = automatic, else an internal tile id (1..4).
+ * act: 0 none, 1 relu, 2 swish.  tile: 0 = heuristic, else an internal tile id (1..ccvpe_op_num_tiles()).
  * iters > 0 additionally times `iters` back-to-back launches with hipEvents and stores the mean
  * milliseconds in *ms. */
+int ccvpe_op_num_tiles(void);
+const char* ccvpe_op_tile_name(int32_t tile);   /* tile ids are 1..ccvpe_op_num_tiles() */
 int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w, const float* bias,
                     int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t act, int32_t tile,
                     float* out, int32_t iters, float* ms, void* stream);

@@ -9,9 +9,8 @@ import torch.nn.functional as F
 
 from ccvpe_amd import _lib
 
-TILES = {1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "256x16m", 6: "128x48m", 7: "128x80m", 8: "256x32"}
-for k, v in list(getattr(_lib, "EXTRA_TILES", {}).items()):
-    TILES[k] = v
+_l = _lib.load()
+TILES = {t: _l.ccvpe_op_tile_name(t).decode().replace("conv_igemm_", "") for t in range(1, _l.ccvpe_op_num_tiles() + 1)}
 
 # (name, B, H, W, Cin, Cout, K)
 SHAPES = [
@@ -44,7 +43,12 @@ def main():
         flops = 2.0 * B * H * W * Cin * Cout * K * K
         ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=K // 2)
         line = f"{name:12s} M={B*H*W:8d} N={Cout:5d} K={Cin*K*K:6d} |"
+        M_, N_ = B * H * W, Cout
         for tid, tn in TILES.items():
+            bm, bn = [int(v) for v in tn.split("_")[0].split("x")]
+            util = (M_ * N_) / (-(-M_ // bm) * bm * -(-N_ // bn) * bn)
+            if util < 0.45:
+                continue
             try:
                 out, ms = _lib.op_conv2d(x, w, b, 1, K // 2, 0, tid, iters=10)
             except Exception as e:  # noqa: BLE001
