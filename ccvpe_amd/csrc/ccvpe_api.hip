@@ -510,10 +510,11 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
             }, 2.0 * B * oh * ow * mid * b.k * b.k, 4.0 * B * mid * ((double)ch * cw + (double)oh * ow));
         }
         Tensor gate = pl.alloc(B, 1, 1, mid);
-        Tensor pooled = pl.alloc(B, 1, 1, mid);
+        const int SC = std::max(1, std::min(16, S / 32));
+        Tensor pooled = pl.alloc(B, 1, SC, mid);
         {
             SeParams sp{};
-            sp.B = B; sp.S = S; sp.C = mid; sp.SQ = bw.sq; sp.inv_hw = 1.f / (float)(oh * ow);
+            sp.B = B; sp.S = S; sp.C = mid; sp.SQ = bw.sq; sp.inv_hw = 1.f / (float)(oh * ow); sp.SC = SC;
             sp.w1 = bw.se_w1; sp.b1 = bw.se_b1; sp.w2 = bw.se_w2; sp.b2 = bw.se_b2;
             pl.add(bn + ".se", {pool, gate, pooled}, [=](const Ctx& c) {
                 SeParams q = sp; q.pool_partial = c.ptr(pool); q.gate = c.ptr(gate); q.pooled = c.ptr(pooled);
@@ -1119,7 +1120,7 @@ int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Ci
     ConvParams p = conv_params(pc, in, Cin, B, H, W, OH, OW, stride, pad, pad, act);
     p.dst[0] = {out, Cout, 0}; p.ndst = 1;
     hipStream_t st = (hipStream_t)stream;
-    launch_conv_igemm(p, tile, st);
+    if (launch_conv_igemm(p, tile, st) != 0) { cleanup(); return fail(CCVPE_EINVAL, "unsupported conv geometry (KH*KW <= 16, Cin %% 8 == 0)"); }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && iters > 0 && ms) {
         hipEvent_t e0, e1;

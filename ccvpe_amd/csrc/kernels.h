@@ -47,6 +47,7 @@ struct ConvParams {
     unsigned gate_bytes;
     int div_cin8_mul;          // filled by launch_conv_igemm: chunk / (Cin/8) == (chunk * mul) >> 20
     int div_kw_mul;            //                              tap / KW       == (tap * mul) >> 5
+    int vec_epi;               // filled by launch_conv_igemm: 16-byte epilogue stores are legal
 };
 
 // tile = 0 picks automatically from (M, N); otherwise one of the TILE_* ids.
@@ -54,7 +55,7 @@ enum { TILE_AUTO = 0 };      // tile ids are 1..conv_igemm_num_tiles()
 int conv_igemm_num_tiles();
 double conv_igemm_tile_util(const ConvParams& p, int tile);
 int conv_igemm_prepare(ConvParams& p);
-void launch_conv_igemm(const ConvParams& p, int tile, hipStream_t s);
+int launch_conv_igemm(const ConvParams& p, int tile, hipStream_t s);   // 0, or -1 for unsupported geometry
 int conv_igemm_npad();       // row padding of packed weights (multiple every tile divides)
 int conv_igemm_last_tile();  // tile id of the most recent launch on this thread (then reset to 0)
 const char* conv_igemm_tile_name(int tile);
@@ -95,7 +96,8 @@ struct SeParams {
     const float* w2;           // [SQ][C] (transposed at pack time)
     const float* b2;           // [C]
     float* gate;               // [B][C] sigmoid(...)
-    float* pooled;             // [B][C] scratch: pooled means
+    float* pooled;             // [B][SC][C] scratch: second-stage partial sums
+    int SC;                    // second-stage split of the S partial rows (<= 16)
 };
 void launch_se(const SeParams& p, hipStream_t s);
 

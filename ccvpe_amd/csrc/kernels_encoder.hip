@@ -171,18 +171,19 @@ void launch_depthwise(const DwParams& p, hipStream_t s) {
 // (2) per sample: 1x1 (C->SQ) + swish -> 1x1 (SQ->C) + sigmoid.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void se_pool_kernel(const SeParams p, float* pooled) {
+    // grid (C/64, B, SC): block z reduces rows z, z+SC, ... of the [S][C] partial sums -> pooled[b][z][c]
     __shared__ float red[4][64];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, z = blockIdx.z, SC = gridDim.z;
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float acc = 0.f;
     if (c < p.C) {
         const float* pp = p.pool_partial + (size_t)b * p.S * p.C + c;
-        for (int s = sl; s < p.S; s += 4) acc += pp[(size_t)s * p.C];
+        for (int s = z * 4 + sl; s < p.S; s += 4 * SC) acc += pp[(size_t)s * p.C];
     }
     red[sl][cl] = acc;
     __syncthreads();
-    if (sl == 0 && c < p.C) pooled[(size_t)b * p.C + c] = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) * p.inv_hw;
+    if (sl == 0 && c < p.C) pooled[((size_t)b * SC + z) * p.C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 
 // grid (ceil(C/256), B): every block recomputes the SQ squeezed values of its sample (C*SQ MACs, cheap)
@@ -191,7 +192,11 @@ __global__ __launch_bounds__(256) void se_mlp_kernel(const SeParams p, const flo
     __shared__ float pooled[1152];
     __shared__ float sq[64];
     const int b = blockIdx.y;
-    for (int c = threadIdx.x; c < p.C; c += 256) pooled[c] = pooled_g[(size_t)b * p.C + c];
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        float acc = 0.f;
+        for (int z = 0; z < p.SC; ++z) acc += pooled_g[((size_t)b * p.SC + z) * p.C + c];
+        pooled[c] = acc * p.inv_hw;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int j = wave; j < p.SQ; j += 4) {
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256) void se_mlp_kernel(const SeParams p, const flo
 }
 
 void launch_se(const SeParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(se_pool_kernel, dim3((p.C + 63) / 64, p.B), dim3(256), 0, s, p, p.pooled);
+    hipLaunchKernelGGL(se_pool_kernel, dim3((p.C + 63) / 64, p.B, p.SC), dim3(256), 0, s, p, p.pooled);
     hipLaunchKernelGGL(se_mlp_kernel, dim3((p.C + 255) / 256, p.B), dim3(256), 0, s, p, (const float*)p.pooled);
 }
 

@@ -197,39 +197,67 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #undef CCVPE_LOAD_TILE
 #undef CCVPE_STORE_TILE
 
-    // ---- epilogue: column n on the lane, rows m in the accumulator registers ----
+    // ---- epilogue ----
+    // (1) accumulators (+bias, activation) -> LDS C tile [BM][BN+4] (the staging buffers are dead now);
+    // (2) rows leave as 16-byte stores: coalesced full rows instead of 4-byte-per-lane column slivers,
+    //     with the residual read and the pixel-shuffle / concat addressing done per float4.
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;
     const int col = lane % MT;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * MT + col;
-        const bool nok = n < p.N;
-        const float bias = nok ? p.bias[n] : 0.f;
-        int q = 0, o = n;
-        if (p.mode == MODE_DECONV) {
-            q = n / p.deconv_cout;
-            o = n - q * p.deconv_cout;
-        }
-        const int dy = q >> 1, dx = q & 1;
+        const int nl = wn * WN + j * MT + col;
+        const int n = n0 + nl;
+        const float bias = n < p.N ? p.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) {
-                const int m = m0 + wm * WM + i * MT + M::row(r, lane);
-                if (!nok || m >= p.M) continue;
-                float v = apply_act(acc[i][j][r] + bias, p.act);
-                int opix = m;
-                if (p.mode == MODE_DECONV) {
+                const int ml = wm * WM + i * MT + M::row(r, lane);
+                Cs[ml * LDC + nl] = apply_act(acc[i][j][r] + bias, p.act);
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    for (int it = tid; it < BM * C4; it += 256) {
+        const int ml = it / C4, c4 = it - ml * C4;
+        const int m = m0 + ml, n = n0 + c4 * 4;
+        if (m >= p.M || n >= p.N) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + c4 * 4);
+        int opix = m, o = n;
+        if (p.mode == MODE_DECONV) {
+            const int q = n / p.deconv_cout;
+            o = n - q * p.deconv_cout;
+            const int x = m % p.W;
+            const int t = m / p.W;
+            const int y = t % p.H;
+            const int b = t / p.H;
+            opix = (b * 2 * p.H + 2 * y + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
+        }
+        if (p.vec_epi) {
+            if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.resid_ld + n);
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                if (d < p.ndst) *reinterpret_cast<f32x4*>(p.dst[d].ptr + (size_t)opix * p.dst[d].ld + p.dst[d].coff + o) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e >= p.N) break;
+                float ve = v[e];
+                int oe = o + e, pe = opix;
+                if (p.mode == MODE_DECONV) {   // a float4 may straddle two (dy,dx) groups when cout % 4 != 0
+                    const int q = (n + e) / p.deconv_cout;
+                    oe = (n + e) - q * p.deconv_cout;
                     const int x = m % p.W;
                     const int t = m / p.W;
-                    const int y = t % p.H;
-                    const int b = t / p.H;
-                    opix = (b * 2 * p.H + 2 * y + dy) * (2 * p.W) + 2 * x + dx;
+                    pe = ((t / p.H) * 2 * p.H + 2 * (t % p.H) + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
                 } else if (p.resid) {
-                    v += p.resid[(size_t)m * p.resid_ld + n];
+                    ve += p.resid[(size_t)m * p.resid_ld + n + e];
                 }
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
-                    if (d < p.ndst) p.dst[d].ptr[(size_t)opix * p.dst[d].ld + p.dst[d].coff + o] = v;
+                    if (d < p.ndst) p.dst[d].ptr[(size_t)pe * p.dst[d].ld + p.dst[d].coff + oe] = ve;
             }
         }
     }
@@ -337,12 +365,15 @@ int conv_igemm_prepare(ConvParams& p) {
     return 0;
 }
 
-void launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
+int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
     ConvParams p = p_in;
-    if (conv_igemm_prepare(p) != 0) return;   // geometry outside the supported range: validated at plan time
+    if (p.KH * p.KW > 16 || p.Cin % 8 || conv_igemm_prepare(p) != 0) return -1;   // geometry outside the supported range
+    p.vec_epi = (p.N % 4 == 0) && (p.resid == nullptr || p.resid_ld % 4 == 0) && (p.mode != MODE_DECONV || p.deconv_cout % 4 == 0);
+    for (int d = 0; d < p.ndst; ++d) p.vec_epi = p.vec_epi && p.dst[d].ld % 4 == 0 && p.dst[d].coff % 4 == 0;
     if (tile < 1 || tile > NTILES) tile = pick_tile(p);
     g_last_tile = tile;
     TILES[tile - 1].launch(p, s);
+    return 0;
 }
 
 }  // namespace ccvpe

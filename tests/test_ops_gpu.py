@@ -1,0 +1,74 @@
+"""Kernel-level parity of the implicit-GEMM convolution (through the C ABI hook ccvpe_op_conv2d) against
+torch's fp32 conv on ragged / odd shapes: M and N not multiples of any tile, every tile id, strides,
+the 2x2 s2 form of the aerial descriptor map, activations.  Tolerance 2e-5 of the output scale."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ccvpe_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # B, H, W, Cin, Cout, K, stride, pad
+    (1, 5, 7, 8, 3, 3, 1, 1),
+    (2, 9, 9, 16, 17, 1, 1, 0),
+    (1, 16, 16, 24, 40, 3, 1, 1),
+    (2, 8, 8, 64, 126, 1, 1, 0),
+    (1, 12, 10, 8, 8, 2, 2, 0),
+    (3, 16, 16, 1280, 64, 2, 2, 0),
+    (1, 33, 17, 40, 96, 3, 1, 1),
+    (2, 31, 29, 104, 80, 3, 1, 1),
+    (1, 64, 64, 16, 16, 3, 1, 1),
+    (1, 7, 4, 320, 1280, 1, 1, 0),
+]
+
+
+def ref_conv(x, w, b, stride, pad, act):
+    y = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=stride, padding=pad)
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = y * torch.sigmoid(y)
+    return y.permute(0, 2, 3, 1).float()
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv2d_matches_torch_auto_tile(shape):
+    B, H, W, Cin, Cout, K, stride, pad = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, K, K, device="cuda", generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    for act in (0, 1, 2):
+        out, _ = _lib.op_conv2d(x, w, b, stride, pad, act, 0)
+        ref = ref_conv(x, w, b, stride, pad, act)
+        assert out.shape == ref.shape
+        err = (out - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-5, f"act {act}: {err:.3g}"
+
+
+def test_every_tile_config_is_correct():
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(2, 19, 23, 40, device="cuda", generator=g)     # M = 874: ragged for every BM
+    w = torch.randn(88, 40, 3, 3, device="cuda", generator=g) / 19.0
+    b = torch.randn(88, device="cuda", generator=g)
+    ref = ref_conv(x, w, b, 1, 1, 0)
+    n = lib.ccvpe_op_num_tiles()
+    assert n >= 8
+    for t in range(1, n + 1):
+        out, _ = _lib.op_conv2d(x, w, b, 1, 1, 0, t)
+        err = (out - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-5, f"tile {t} ({lib.ccvpe_op_tile_name(t).decode()}): {err:.3g}"
+
+
+def test_conv2d_rejects_bad_geometry():
+    x = torch.randn(1, 4, 4, 12, device="cuda")
+    w = torch.randn(4, 12, 1, 1, device="cuda")
+    with pytest.raises(_lib.CcvpeError):
+        _lib.op_conv2d(x, w)              # Cin not a multiple of 8
+    x = torch.randn(1, 8, 8, 8, device="cuda")
+    w = torch.randn(4, 8, 5, 5, device="cuda")
+    with pytest.raises(_lib.CcvpeError):
+        _lib.op_conv2d(x, w, pad=2)       # 25 taps: outside the kernel's tap table
