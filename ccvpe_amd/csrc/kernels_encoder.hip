@@ -198,19 +198,45 @@ __global__ __launch_bounds__(256) void se_mlp_kernel(const SeParams p, const flo
         pooled[c] = acc * p.inv_hw;
     }
     __syncthreads();
+    // squeeze: wave w owns j = w, w+4, ...; four j at a time with the lane's pooled values in registers so
+    // that 4 x 18 weight loads are in flight together (a plain loop serialises on L2 latency)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = wave; j < p.SQ; j += 4) {
-        float acc = 0.f;
-        for (int c = lane; c < p.C; c += 64) acc = fmaf(p.w1[j * p.C + c], pooled[c], acc);
+    float pv[18];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        if (lane == 0) sq[j] = swishf(acc + p.b1[j]);
+    for (int k = 0; k < 18; ++k) pv[k] = (lane + 64 * k) < p.C ? pooled[lane + 64 * k] : 0.f;
+    for (int j0 = wave; j0 < p.SQ; j0 += 16) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+            const int c = lane + 64 * k;
+            if (c < p.C) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 4 * u;
+                    if (j < p.SQ) acc[u] = fmaf(p.w1[(size_t)j * p.C + c], pv[k], acc[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float a = acc[u];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+            const int j = j0 + 4 * u;
+            if (lane == 0 && j < p.SQ) sq[j] = swishf(a + p.b1[j]);
+        }
     }
     __syncthreads();
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < p.C) {
         float acc = p.b2[c];
-        for (int j = 0; j < p.SQ; ++j) acc = fmaf(p.w2[(size_t)j * p.C + c], sq[j], acc);
+        for (int j = 0; j < p.SQ; j += 8) {
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = (j + u) < p.SQ ? p.w2[(size_t)(j + u) * p.C + c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(w[u], (j + u) < p.SQ ? sq[j + u] : 0.f, acc);
+        }
         p.gate[(size_t)b * p.C + c] = 1.f / (1.f + __expf(-acc));
     }
 }
