@@ -512,12 +512,13 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         Tensor gate = pl.alloc(B, 1, 1, mid);
         const int SC = std::max(1, std::min(16, S / 32));
         Tensor pooled = pl.alloc(B, 1, SC, mid);
+        Tensor sqt = pl.alloc(B, 1, 1, 64);
         {
             SeParams sp{};
             sp.B = B; sp.S = S; sp.C = mid; sp.SQ = bw.sq; sp.inv_hw = 1.f / (float)(oh * ow); sp.SC = SC;
             sp.w1 = bw.se_w1; sp.b1 = bw.se_b1; sp.w2 = bw.se_w2; sp.b2 = bw.se_b2;
-            pl.add(bn + ".se", {pool, gate, pooled}, [=](const Ctx& c) {
-                SeParams q = sp; q.pool_partial = c.ptr(pool); q.gate = c.ptr(gate); q.pooled = c.ptr(pooled);
+            pl.add(bn + ".se", {pool, gate, pooled, sqt}, [=](const Ctx& c) {
+                SeParams q = sp; q.pool_partial = c.ptr(pool); q.gate = c.ptr(gate); q.pooled = c.ptr(pooled); q.sq = c.ptr(sqt);
                 launch_se(q, c.stream);
             }, 4.0 * B * mid * bw.sq, 4.0 * B * S * mid);
         }

@@ -98,6 +98,7 @@ struct SeParams {
     float* gate;               // [B][C] sigmoid(...)
     float* pooled;             // [B][SC][C] scratch: second-stage partial sums
     int SC;                    // second-stage split of the S partial rows (<= 16)
+    float* sq;                 // [B][SQ] scratch: squeezed activations
 };
 void launch_se(const SeParams& p, hipStream_t s);
 

@@ -186,64 +186,48 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const SeParams p, float* p
     if (sl == 0 && c < p.C) pooled[((size_t)b * SC + z) * p.C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 
-// grid (ceil(C/256), B): every block recomputes the SQ squeezed values of its sample (C*SQ MACs, cheap)
-// and produces 256 gates; w2t is [SQ][C] so consecutive lanes read consecutive channels.
-__global__ __launch_bounds__(256) void se_mlp_kernel(const SeParams p, const float* pooled_g) {
-    __shared__ float pooled[1152];
+// squeeze: grid (SQ, B), one block per (j, sample): 256 threads reduce over C (<= 5 loads each)
+__global__ __launch_bounds__(256) void se_squeeze_kernel(const SeParams p, const float* pooled_g, float* sq_g) {
+    __shared__ float red[4];
+    const int j = blockIdx.x, b = blockIdx.y;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        float pv = 0.f;
+        for (int z = 0; z < p.SC; ++z) pv += pooled_g[((size_t)b * p.SC + z) * p.C + c];
+        acc = fmaf(p.w1[(size_t)j * p.C + c], pv * p.inv_hw, acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sq_g[(size_t)b * p.SQ + j] = swishf(red[0] + red[1] + red[2] + red[3] + p.b1[j]);
+}
+
+// excite: grid (ceil(C/256), B), thread per channel; w2 is [SQ][C] so lanes read consecutive channels
+__global__ __launch_bounds__(256) void se_excite_kernel(const SeParams p, const float* sq_g) {
     __shared__ float sq[64];
     const int b = blockIdx.y;
-    for (int c = threadIdx.x; c < p.C; c += 256) {
-        float acc = 0.f;
-        for (int z = 0; z < p.SC; ++z) acc += pooled_g[((size_t)b * p.SC + z) * p.C + c];
-        pooled[c] = acc * p.inv_hw;
-    }
-    __syncthreads();
-    // squeeze: wave w owns j = w, w+4, ...; four j at a time with the lane's pooled values in registers so
-    // that 4 x 18 weight loads are in flight together (a plain loop serialises on L2 latency)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float pv[18];
-#pragma unroll
-    for (int k = 0; k < 18; ++k) pv[k] = (lane + 64 * k) < p.C ? pooled[lane + 64 * k] : 0.f;
-    for (int j0 = wave; j0 < p.SQ; j0 += 16) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 18; ++k) {
-            const int c = lane + 64 * k;
-            if (c < p.C) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + 4 * u;
-                    if (j < p.SQ) acc[u] = fmaf(p.w1[(size_t)j * p.C + c], pv[k], acc[u]);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float a = acc[u];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-            const int j = j0 + 4 * u;
-            if (lane == 0 && j < p.SQ) sq[j] = swishf(a + p.b1[j]);
-        }
-    }
+    if (threadIdx.x < p.SQ) sq[threadIdx.x] = sq_g[(size_t)b * p.SQ + threadIdx.x];
     __syncthreads();
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < p.C) {
-        float acc = p.b2[c];
-        for (int j = 0; j < p.SQ; j += 8) {
-            float w[8];
+    if (c >= p.C) return;
+    float acc = p.b2[c];
+    int j = 0;
+    for (; j + 8 <= p.SQ; j += 8) {
+        float w[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = (j + u) < p.SQ ? p.w2[(size_t)(j + u) * p.C + c] : 0.f;
+        for (int u = 0; u < 8; ++u) w[u] = p.w2[(size_t)(j + u) * p.C + c];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = fmaf(w[u], (j + u) < p.SQ ? sq[j + u] : 0.f, acc);
-        }
-        p.gate[(size_t)b * p.C + c] = 1.f / (1.f + __expf(-acc));
+        for (int u = 0; u < 8; ++u) acc = fmaf(w[u], sq[j + u], acc);
     }
+    for (; j < p.SQ; ++j) acc = fmaf(p.w2[(size_t)j * p.C + c], sq[j], acc);
+    p.gate[(size_t)b * p.C + c] = 1.f / (1.f + __expf(-acc));
 }
 
 void launch_se(const SeParams& p, hipStream_t s) {
     hipLaunchKernelGGL(se_pool_kernel, dim3((p.C + 63) / 64, p.B, p.SC), dim3(256), 0, s, p, p.pooled);
-    hipLaunchKernelGGL(se_mlp_kernel, dim3((p.C + 255) / 256, p.B), dim3(256), 0, s, p, (const float*)p.pooled);
+    hipLaunchKernelGGL(se_squeeze_kernel, dim3(p.SQ, p.B), dim3(256), 0, s, p, (const float*)p.pooled, p.sq);
+    hipLaunchKernelGGL(se_excite_kernel, dim3((p.C + 255) / 256, p.B), dim3(256), 0, s, p, (const float*)p.sq);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -166,4 +166,5 @@ def test_reload_state_dict_changes_result():
     assert not torch.allclose(a, b)
     m.load_state_dict(weights.generate_state_dict("oxford", cfg["seed"]))
     c = m(g, s)[0]
-    assert torch.equal(a, c)
+    # re-ingesting the weights re-tunes the per-layer tiles, which may change the summation order
+    assert (a - c).abs().max().item() <= 2e-5 * a.abs().max().item()
