@@ -83,6 +83,14 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    try:   # rebuild when the sources are newer than the library (hipcc cross-compiles in seconds)
+        from . import build as _build
+        if not _build.is_current():
+            _build.build(verbose=False)
+    except Exception as e:  # noqa: BLE001 - no hipcc here: fall through to whatever library exists
+        if os.path.exists(LIB_PATH):
+            import warnings
+            warnings.warn(f"libccvpe_hip.so may be stale and could not be rebuilt: {e}")
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -m ccvpe_amd.build` (hipcc, gfx950). "

@@ -36,12 +36,17 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def is_current() -> bool:
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+        return False
+    with open(STAMP) as fh:
+        return fh.read().strip() == _digest()
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
-        with open(STAMP) as fh:
-            if fh.read().strip() == dig:
-                return LIB
+    if not force and is_current():
+        return LIB
     objs = []
     procs = []
     for src in SOURCES:
