@@ -142,7 +142,14 @@ struct Ctx {
     const float* grd = nullptr;
     const float* sat = nullptr;
     ccvpe_outputs out{};
+    float* splitk_scratch = nullptr;
+    size_t splitk_floats = 0;
     float* ptr(const Tensor& t) const { return arena + (*off)[t.id]; }
+    void launch_conv(ConvParams& p, int cfg) const {
+        p.partial = splitk_scratch;
+        p.partial_floats = splitk_floats;
+        launch_conv_igemm(p, cfg, stream);
+    }
 };
 
 struct Op {
@@ -152,7 +159,7 @@ struct Op {
     double flops = 0, bytes = 0;
     // implicit-GEMM launches: tile id the launch uses (0 = heuristic) - set by Plan::autotune
     std::shared_ptr<int> tile;
-    int gemm_m = 0, gemm_n = 0;
+    int gemm_m = 0, gemm_n = 0, gemm_kpad = 0;
 };
 
 struct TapInfo { Tensor t; int coff; int C; };
@@ -166,6 +173,8 @@ struct Plan {
     std::map<std::string, TapInfo> taps;
     size_t total = 0;             // floats
     float* arena = nullptr;
+    Tensor scratch;               // split-K slab scratch shared by every conv launch (whole-plan lifetime)
+    static constexpr size_t SPLITK_FLOATS = 16u << 20;   // 64 MiB: 16 slabs of M*N <= 1M outputs
 
     Tensor alloc(int B_, int H, int W, int C) {
         Tensor t; t.id = (int)size.size(); t.B = B_; t.H = H; t.W = W; t.C = C;
@@ -177,13 +186,14 @@ struct Plan {
         for (auto& t : uses) o.uses.push_back(t.id);
         ops.push_back(std::move(o));
     }
-    void add_conv(const std::string& name, std::vector<Tensor> uses, int gemm_m, int gemm_n,
+    void add_conv(const std::string& name, std::vector<Tensor> uses, int gemm_m, int gemm_n, int gemm_kpad,
                   std::function<void(const Ctx&, int)> fn, double flops, double bytes) {
         auto tp = std::make_shared<int>(TILE_AUTO);
         add(name, std::move(uses), [fn, tp](const Ctx& c) { fn(c, *tp); }, flops, bytes);
         ops.back().tile = tp;
         ops.back().gemm_m = gemm_m;
         ops.back().gemm_n = gemm_n;
+        ops.back().gemm_kpad = gemm_kpad;
     }
     void assign() {
         const int n = (int)size.size();
@@ -191,6 +201,7 @@ struct Plan {
         for (int i = 0; i < (int)ops.size(); ++i)
             for (int id : ops[i].uses) { first[id] = std::min(first[id], i); last[id] = std::max(last[id], i); }
         if (debug) for (int i = 0; i < n; ++i) last[i] = 1 << 30;
+        if (scratch.id >= 0) { first[scratch.id] = 0; last[scratch.id] = 1 << 30; }
         off.assign(n, 0);
         std::vector<int> order(n);
         for (int i = 0; i < n; ++i) order[i] = i;
@@ -489,10 +500,10 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
             e = pl.alloc(B, ch, cw, mid);
             const PackedConv* pc = &bw.expand;
             const int hh = ch, ww = cw;
-            pl.add_conv(bn + ".expand", {xin, e}, B * hh * ww, pc->N, [=](const Ctx& c, int tile) {
+            pl.add_conv(bn + ".expand", {xin, e}, B * hh * ww, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(xin), xin.C, B, hh, ww, hh, ww, 1, 0, 0, ACT_SWISH);
                 p.dst[0] = {c.ptr(e), mid, 0}; p.ndst = 1;
-                launch_conv_igemm(p, tile, c.stream);
+                c.launch_conv(p, tile);
             }, 2.0 * B * ch * cw * b.cin * mid, 4.0 * B * ch * cw * (b.cin + mid));
         }
         static_pad(b.k, b.s, lo, hi);
@@ -531,13 +542,13 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
             std::vector<Tensor> uses = {d, gate, o};
             if (skip) uses.push_back(xin);
             for (int t = 0; t < td.n; ++t) uses.push_back(td.t[t]);
-            pl.add_conv(bn + ".project", uses, B * oh * ow, pc->N, [=](const Ctx& c, int tile) {
+            pl.add_conv(bn + ".project", uses, B * oh * ow, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(d), mid, B, oh, ow, oh, ow, 1, 0, 0, ACT_NONE);
                 p.gate = c.ptr(gate);
                 if (skip) { p.resid = c.ptr(xin); p.resid_ld = xin.C; }
                 p.dst[0] = {c.ptr(o), o.C, 0}; p.ndst = 1;
                 for (int t = 0; t < td.n; ++t) p.dst[p.ndst++] = {c.ptr(td.t[t]), td.t[t].C, td.coff[t]};
-                launch_conv_igemm(p, tile, c.stream);
+                c.launch_conv(p, tile);
             }, 2.0 * B * oh * ow * mid * b.cout, 4.0 * B * oh * ow * (mid + b.cout * (1 + td.n)));
         }
         out.tap[i] = o;
@@ -549,10 +560,10 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         const PackedConv* pc = &ew.head;
         Tensor x = cur;
         const int hh = ch, ww = cw;
-        pl.add_conv(tag + ".head", {x, vol}, B * hh * ww, pc->N, [=](const Ctx& c, int tile) {
+        pl.add_conv(tag + ".head", {x, vol}, B * hh * ww, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
             ConvParams p = conv_params(*pc, c.ptr(x), x.C, B, hh, ww, hh, ww, 1, 0, 0, ACT_SWISH);
             p.dst[0] = {c.ptr(vol), 1280, 0}; p.ndst = 1;
-            launch_conv_igemm(p, tile, c.stream);
+            c.launch_conv(p, tile);
         }, 2.0 * B * ch * cw * 320 * 1280, 4.0 * B * ch * cw * 1600);
     }
     out.vol = vol;
@@ -562,6 +573,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
 static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
     const VariantSpec& vs = h->vs;
     pl.B = B; pl.gh = gh; pl.gw = gw; pl.debug = h->debug;
+    pl.scratch = pl.alloc(1, 1, 1, (int)Plan::SPLITK_FLOATS);
 
     // ---- geometry of the ground feature volume ----
     int fh = conv_out(gh, 3, 2), fw = conv_out(gw, 3, 2);
@@ -608,10 +620,10 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
     {
         const PackedConv* pc = &h->grd_heads;
         Tensor x = genc.vol;
-        pl.add_conv("grd.heads", {x, ghead}, B * fh * fw, pc->N, [=](const Ctx& c, int tile) {
+        pl.add_conv("grd.heads", {x, ghead}, B * fh * fw, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
             ConvParams p = conv_params(*pc, c.ptr(x), 1280, B, fh, fw, fh, fw, 1, 0, 0, ACT_NONE);
             p.dst[0] = {c.ptr(ghead), ntot, 0}; p.ndst = 1;
-            launch_conv_igemm(p, tile, c.stream);
+            c.launch_conv(p, tile);
         }, 2.0 * B * fh * fw * 1280 * ntot, 4.0 * B * fh * fw * (1280 + ntot));
         GrdDescParams gp{};
         gp.B = B; gp.Hf = fh; gp.Wf = fw; gp.Ntot = ntot; gp.nlev = 6; gp.Ltot = ltot;
@@ -628,10 +640,10 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
     {
         const PackedConv* pc = &h->sat_desc;
         Tensor x = senc.vol;
-        pl.add_conv("sat.descmap", {x, dmap}, B * 8 * 8, pc->N, [=](const Ctx& c, int tile) {
+        pl.add_conv("sat.descmap", {x, dmap}, B * 8 * 8, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
             ConvParams p = conv_params(*pc, c.ptr(x), 1280, B, 16, 16, 8, 8, 2, 0, 0, ACT_NONE);
             p.dst[0] = {c.ptr(dmap), D, 0}; p.ndst = 1;
-            launch_conv_igemm(p, tile, c.stream);
+            c.launch_conv(p, tile);
         }, 2.0 * B * 64 * 5120.0 * D, 4.0 * (B * 256 * 1280.0 + 5120.0 * D));
         pl.taps["sat_descriptor_map"] = {dmap, 0, D};
     }
@@ -643,30 +655,30 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
         {
             const PackedConv* pc = &dw.deconv[j];
             const int cout = l.dout;
-            pl.add_conv(tag + ".deconv", {din, cat}, B * hin * hin, pc->N, [=](const Ctx& c, int tile) {
+            pl.add_conv(tag + ".deconv", {din, cat}, B * hin * hin, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(din), din.C, B, hin, hin, hin, hin, 1, 0, 0, ACT_NONE);
                 p.mode = MODE_DECONV; p.deconv_cout = cout;
                 p.dst[0] = {c.ptr(cat), cat.C, 0}; p.ndst = 1;
-                launch_conv_igemm(p, tile, c.stream);
+                c.launch_conv(p, tile);
             }, 2.0 * B * hin * hin * (double)l.din * 4 * l.dout, 4.0 * B * hin * hin * ((double)din.C + 4.0 * l.dout));
         }
         Tensor mid = pl.alloc(B, hout, hout, l.mid);
         {
             const PackedConv* pc = &dw.conva[j];
-            pl.add_conv(tag + ".conv_a", {cat, mid}, B * hout * hout, pc->N, [=](const Ctx& c, int tile) {
+            pl.add_conv(tag + ".conv_a", {cat, mid}, B * hout * hout, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(cat), cat.C, B, hout, hout, hout, hout, 1, 1, 1, ACT_RELU);
                 p.dst[0] = {c.ptr(mid), mid.C, 0}; p.ndst = 1;
-                launch_conv_igemm(p, tile, c.stream);
+                c.launch_conv(p, tile);
             }, 2.0 * B * hout * hout * 9.0 * cat.C * l.mid, 4.0 * B * hout * hout * ((double)cat.C + l.mid));
         }
         if (j == 5) return mid;   // tail conv handled by the caller
         Tensor o = pl.alloc(B, hout, hout, l.out);
         {
             const PackedConv* pc = &dw.convb[j];
-            pl.add_conv(tag + ".conv_b", {mid, o}, B * hout * hout, pc->N, [=](const Ctx& c, int tile) {
+            pl.add_conv(tag + ".conv_b", {mid, o}, B * hout * hout, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(mid), mid.C, B, hout, hout, hout, hout, 1, 1, 1, ACT_NONE);
                 p.dst[0] = {c.ptr(o), o.C, 0}; p.ndst = 1;
-                launch_conv_igemm(p, tile, c.stream);
+                c.launch_conv(p, tile);
             }, 2.0 * B * hout * hout * 9.0 * l.mid * l.out, 4.0 * B * hout * hout * ((double)l.mid + l.out));
         }
         return o;
@@ -892,6 +904,7 @@ int ccvpe_output_channels(ccvpe_handle h, int32_t level) {
 static int autotune_plan(ccvpe_handle h, Plan& pl) {
     Ctx c;
     c.arena = h->arena; c.off = &pl.off; c.stream = nullptr;
+    c.splitk_scratch = c.ptr(pl.scratch); c.splitk_floats = Plan::SPLITK_FLOATS;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -903,18 +916,27 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
         q.M = op.gemm_m; q.N = op.gemm_n;
         int best = 0;
         float best_ms = 1e30f;
+        const int nkt = op.gemm_kpad / 32;
         for (int t = 1; t <= nt; ++t) {
             if (conv_igemm_tile_util(q, t) < 0.45) continue;
-            *op.tile = t;
-            op.fn(c);   // warm-up (also sets the dynamic-LDS attribute on first use)
-            HIPCHK(hipEventRecord(e0, nullptr));
-            op.fn(c);
-            op.fn(c);
-            HIPCHK(hipEventRecord(e1, nullptr));
-            HIPCHK(hipEventSynchronize(e1));
-            float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-            if (ms < best_ms) { best_ms = ms; best = t; }
+            const long long blocks = conv_igemm_tile_blocks(q, t);
+            for (int split = 1; split <= 16; split *= 2) {
+                if (split > 1) {   // split-K only where the grid underfills the chip and K is deep enough
+                    if (blocks >= 512 || blocks * split > 2048 || nkt < 4 * split) break;
+                    if ((size_t)split * op.gemm_m * op.gemm_n > Plan::SPLITK_FLOATS) break;
+                }
+                const int cfg = t | (split << 8);
+                *op.tile = cfg;
+                op.fn(c);   // warm-up (also sets the dynamic-LDS attribute on first use)
+                HIPCHK(hipEventRecord(e0, nullptr));
+                op.fn(c);
+                op.fn(c);
+                HIPCHK(hipEventRecord(e1, nullptr));
+                HIPCHK(hipEventSynchronize(e1));
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best_ms) { best_ms = ms; best = cfg; }
+            }
         }
         *op.tile = best;
     }
@@ -983,6 +1005,7 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
         if (rc) return rc;
         Ctx c;
         c.arena = h->arena; c.off = &pl->off; c.stream = stream;
+        c.splitk_scratch = c.ptr(pl->scratch); c.splitk_floats = Plan::SPLITK_FLOATS;
         c.grd = grd + (size_t)done * 3 * gh * gw;
         c.sat = sat + (size_t)done * 3 * CCVPE_SAT_HW * CCVPE_SAT_HW;
         c.out.logits_flattened = out->logits_flattened + done * npx;
@@ -1008,7 +1031,10 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
                 HIPCHK(hipEventElapsedTime(&ms, e0, e1));
                 const int tile = conv_igemm_last_tile();
                 std::string nm = op.name;
-                if (tile) nm += std::string("|") + conv_igemm_tile_name(tile);
+                if (tile) {
+                    nm += std::string("|") + conv_igemm_tile_name(tile);
+                    if ((tile >> 8) > 1) nm += "_splitk" + std::to_string(tile >> 8);
+                }
                 h->prof.push_back({nm, ms, op.flops, op.bytes});
             }
             (void)hipEventDestroy(e0);

@@ -48,12 +48,16 @@ struct ConvParams {
     int div_cin8_mul;          // filled by launch_conv_igemm: chunk / (Cin/8) == (chunk * mul) >> 20
     int div_kw_mul;            //                              tap / KW       == (tap * mul) >> 5
     int vec_epi;               // filled by launch_conv_igemm: 16-byte epilogue stores are legal
+    int splitk;                // filled by launch_conv_igemm from the cfg word: K split over gridDim.z
+    float* partial;            // split-K slab scratch [splitk][M][N] (null = split-K unavailable)
+    size_t partial_floats;
 };
 
 // tile = 0 picks automatically from (M, N); otherwise one of the TILE_* ids.
-enum { TILE_AUTO = 0 };      // tile ids are 1..conv_igemm_num_tiles()
+enum { TILE_AUTO = 0 };      // tile ids are 1..conv_igemm_num_tiles(); a launch cfg word is tile | (splitk << 8)
 int conv_igemm_num_tiles();
 double conv_igemm_tile_util(const ConvParams& p, int tile);
+long long conv_igemm_tile_blocks(const ConvParams& p, int tile);
 int conv_igemm_prepare(ConvParams& p);
 int launch_conv_igemm(const ConvParams& p, int tile, hipStream_t s);   // 0, or -1 for unsupported geometry
 int conv_igemm_npad();       // row padding of packed weights (multiple every tile divides)

@@ -18,6 +18,8 @@
 // MFMAs: lane l holds k = 4*(l / MT) + j of its row for j = 0..3, the same k permutation on A and B.
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace ccvpe {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -46,6 +48,46 @@ template <> struct Mfma<16> {
     static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ int row(int r, int lane) { return (lane >> 4) * 4 + r; }
 };
+
+// Final placement of 4 consecutive output channels (n .. n+3) of GEMM row m: residual add, k2s2
+// pixel-shuffle addressing for the transposed conv, up to 3 concat destinations; 16-byte stores when legal.
+__device__ __forceinline__ void emit_out4(const ConvParams& p, int m, int n, f32x4 v) {
+    int opix = m, o = n;
+    if (p.mode == MODE_DECONV) {
+        const int q = n / p.deconv_cout;
+        o = n - q * p.deconv_cout;
+        const int x = m % p.W;
+        const int t = m / p.W;
+        const int y = t % p.H;
+        const int b = t / p.H;
+        opix = (b * 2 * p.H + 2 * y + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
+    }
+    if (p.vec_epi) {
+        if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.resid_ld + n);
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < p.ndst) *reinterpret_cast<f32x4*>(p.dst[d].ptr + (size_t)opix * p.dst[d].ld + p.dst[d].coff + o) = v;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n + e >= p.N) break;
+            float ve = v[e];
+            int oe = o + e, pe = opix;
+            if (p.mode == MODE_DECONV) {   // a float4 may straddle two (dy,dx) groups when cout % 4 != 0
+                const int q = (n + e) / p.deconv_cout;
+                oe = (n + e) - q * p.deconv_cout;
+                const int x = m % p.W;
+                const int t = m / p.W;
+                pe = ((t / p.H) * 2 * p.H + 2 * (t % p.H) + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
+            } else if (p.resid) {
+                ve += p.resid[(size_t)m * p.resid_ld + n + e];
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                if (d < p.ndst) p.dst[d].ptr[(size_t)pe * p.dst[d].ld + p.dst[d].coff + oe] = ve;
+        }
+    }
+}
 
 template <int BM, int BN, int WGM, int WGN, int MT, bool GATE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
@@ -146,8 +188,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) acc[i][j][r] = 0.f;
 
-    const int nkt = p.Kpad / BK;
-    CCVPE_LOAD_TILE(0);
+    // split-K: blockIdx.z owns K tiles [kt0, kt1); raw partial sums go to a slab, splitk_reduce_kernel finishes
+    const int nkt_all = p.Kpad / BK;
+    int kt0 = 0, kt1 = nkt_all;
+    if (p.splitk > 1) {
+        const int per = (nkt_all + p.splitk - 1) / p.splitk;
+        kt0 = min((int)blockIdx.z * per, nkt_all);
+        kt1 = min(kt0 + per, nkt_all);
+    }
+    {
+        const int kfirst = min(kt0, nkt_all - 1);
+        CCVPE_LOAD_TILE(kfirst);
+    }
     CCVPE_STORE_TILE(0);
     __syncthreads();
 
@@ -155,11 +207,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int b_row = wn * WN + (lane % MT);
     const int k_lane = (lane / MT) * 4;
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int stage = kt & 1;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int stage = (kt - kt0) & 1;
         // unconditional prefetch: the last iteration re-reads its own tile into the idle stage, which keeps
         // the loop free of branches (and the staging registers out of scratch)
-        const int ktn = min(kt + 1, nkt - 1);
+        const int ktn = min(kt + 1, kt1 - 1);
         CCVPE_LOAD_TILE(ktn);
         // keep the prefetch ABOVE the MFMA block: without this fence hipcc sinks the loads to just before
         // the ds_writes (to shorten register live ranges) and every K tile eats a full memory latency
@@ -203,18 +255,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     //     with the residual read and the pixel-shuffle / concat addressing done per float4.
     constexpr int LDC = BN + 4;
     float* Cs = smem;
+    const bool split = p.splitk > 1;
     const int col = lane % MT;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nl = wn * WN + j * MT + col;
         const int n = n0 + nl;
-        const float bias = n < p.N ? p.bias[n] : 0.f;
+        const float bias = (!split && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) {
                 const int ml = wm * WM + i * MT + M::row(r, lane);
-                Cs[ml * LDC + nl] = apply_act(acc[i][j][r] + bias, p.act);
+                const float v = acc[i][j][r] + bias;
+                Cs[ml * LDC + nl] = split ? v : apply_act(v, p.act);
             }
         }
     }
@@ -224,42 +278,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int ml = it / C4, c4 = it - ml * C4;
         const int m = m0 + ml, n = n0 + c4 * 4;
         if (m >= p.M || n >= p.N) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + c4 * 4);
-        int opix = m, o = n;
-        if (p.mode == MODE_DECONV) {
-            const int q = n / p.deconv_cout;
-            o = n - q * p.deconv_cout;
-            const int x = m % p.W;
-            const int t = m / p.W;
-            const int y = t % p.H;
-            const int b = t / p.H;
-            opix = (b * 2 * p.H + 2 * y + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
-        }
-        if (p.vec_epi) {
-            if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.resid_ld + n);
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-                if (d < p.ndst) *reinterpret_cast<f32x4*>(p.dst[d].ptr + (size_t)opix * p.dst[d].ld + p.dst[d].coff + o) = v;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + c4 * 4);
+        if (split) {
+            float* dst = p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n;
+            if ((p.N & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+            else
+                for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = v[e];
         } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (n + e >= p.N) break;
-                float ve = v[e];
-                int oe = o + e, pe = opix;
-                if (p.mode == MODE_DECONV) {   // a float4 may straddle two (dy,dx) groups when cout % 4 != 0
-                    const int q = (n + e) / p.deconv_cout;
-                    oe = (n + e) - q * p.deconv_cout;
-                    const int x = m % p.W;
-                    const int t = m / p.W;
-                    pe = ((t / p.H) * 2 * p.H + 2 * (t % p.H) + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
-                } else if (p.resid) {
-                    ve += p.resid[(size_t)m * p.resid_ld + n + e];
-                }
-#pragma unroll
-                for (int d = 0; d < 3; ++d)
-                    if (d < p.ndst) p.dst[d].ptr[(size_t)pe * p.dst[d].ld + p.dst[d].coff + oe] = ve;
-            }
+            emit_out4(p, m, n, v);
         }
+    }
+}
+
+// second half of a split-K launch: sum the slabs, then bias / activation / placement as the fused epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
+    const int n4 = (p.N + 3) >> 2;
+    const long long total = (long long)p.M * n4;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+        const int m = (int)(it / n4);
+        const int n = (int)(it - (long long)m * n4) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < p.splitk; ++z) {
+            const float* src = p.partial + ((size_t)z * p.M + m) * p.N + n;
+            if ((p.N & 3) == 0) v += *reinterpret_cast<const f32x4*>(src);
+            else
+                for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += src[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] + (n + e < p.N ? p.bias[n + e] : 0.f), p.act);
+        emit_out4(p, m, n, v);
     }
 }
 
@@ -272,8 +319,13 @@ static void launch_cfg2(const ConvParams& p, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.splitk > 1 ? p.splitk : 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    if (p.splitk > 1) {
+        const long long total = (long long)p.M * ((p.N + 3) / 4);
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+    }
 }
 
 template <int BM, int BN, int WGM, int WGN, int MT>
@@ -318,6 +370,12 @@ double conv_igemm_tile_util(const ConvParams& p, int tile) {
     return ((double)p.M * p.N) / (gm * c.bm * gn * c.bn);
 }
 
+long long conv_igemm_tile_blocks(const ConvParams& p, int tile) {
+    if (tile < 1 || tile > NTILES) return 0;
+    const TileCfg& c = TILES[tile - 1];
+    return (long long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
+}
+
 static int pick_tile(const ConvParams& p) {
     const double cus = 256.0;
     int best = 3;
@@ -337,7 +395,7 @@ static int pick_tile(const ConvParams& p) {
 
 static thread_local int g_last_tile = 0;
 int conv_igemm_last_tile() { int t = g_last_tile; g_last_tile = 0; return t; }
-const char* conv_igemm_tile_name(int tile) { return (tile >= 1 && tile <= NTILES) ? TILES[tile - 1].name : ""; }
+const char* conv_igemm_tile_name(int tile) { tile &= 0xff; return (tile >= 1 && tile <= NTILES) ? TILES[tile - 1].name : ""; }
 
 // exact small-range division by multiplication: q = (g * mul) >> 20 for 0 <= g < limit
 static int find_div_mul(int d, int limit) {
@@ -370,8 +428,12 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
     if (p.KH * p.KW > 16 || p.Cin % 8 || conv_igemm_prepare(p) != 0) return -1;   // geometry outside the supported range
     p.vec_epi = (p.N % 4 == 0) && (p.resid == nullptr || p.resid_ld % 4 == 0) && (p.mode != MODE_DECONV || p.deconv_cout % 4 == 0);
     for (int d = 0; d < p.ndst; ++d) p.vec_epi = p.vec_epi && p.dst[d].ld % 4 == 0 && p.dst[d].coff % 4 == 0;
+    int splitk = (tile >> 8) & 0xff;
+    tile &= 0xff;
     if (tile < 1 || tile > NTILES) tile = pick_tile(p);
-    g_last_tile = tile;
+    if (splitk < 2 || p.partial == nullptr || (size_t)splitk * p.M * p.N > p.partial_floats) splitk = 1;
+    p.splitk = splitk;
+    g_last_tile = tile | (splitk << 8);
     TILES[tile - 1].launch(p, s);
     return 0;
 }
