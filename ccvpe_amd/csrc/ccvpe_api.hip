@@ -250,6 +250,7 @@ struct ccvpe_handle_s {
     bool debug = false;
     bool autotune = true;
     int graph_mode = -1;          // -1 auto (plans of <= 4 samples replay a hipGraph), 0 never, 1 always
+    hipStream_t capture_stream = nullptr;
     std::vector<void*> dev_allocs;
     EncoderW grd_enc, sat_enc;
     PackedConv grd_heads, sat_desc;
@@ -838,6 +839,8 @@ int ccvpe_destroy(ccvpe_handle h) {
     (void)hipSetDevice(h->cfg.device);
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->arena) (void)hipFree(h->arena);
+    h->plans.clear();
+    if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     delete h;
     return 0;
 }
@@ -1049,10 +1052,14 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
             HIPCHK(hipMemcpyAsync((void*)c.grd, ugrd, (size_t)mb * 3 * gh * gw * sizeof(float), hipMemcpyDeviceToDevice, stream));
             HIPCHK(hipMemcpyAsync((void*)c.sat, usat, (size_t)mb * 3 * CCVPE_SAT_HW * CCVPE_SAT_HW * sizeof(float), hipMemcpyDeviceToDevice, stream));
             if (!pl->exec && pl->runs >= 1) {   // first call ran eagerly (lazy kernel attributes are set): capture now
+                // capture on a private stream (the caller's may be the legacy null stream, which cannot capture)
                 hipGraph_t graph = nullptr;
-                HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-                for (auto& op : pl->ops) op.fn(c);
-                hipError_t ce = hipStreamEndCapture(stream, &graph);
+                if (!h->capture_stream) HIPCHK(hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking));
+                HIPCHK(hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal));
+                Ctx cc = c;
+                cc.stream = h->capture_stream;
+                for (auto& op : pl->ops) op.fn(cc);
+                hipError_t ce = hipStreamEndCapture(h->capture_stream, &graph);
                 if (ce == hipSuccess && graph) {
                     hipGraphExec_t ex = nullptr;
                     if (hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0) == hipSuccess) pl->exec = ex;
