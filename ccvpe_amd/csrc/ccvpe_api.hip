@@ -131,6 +131,9 @@ struct DecoderW {
     PackedConv deconv[6], conva[6], convb[5];
     float* tail_w = nullptr;
     float tail_b[2] = {0.f, 0.f};
+    // fused last level (kernels_level1.hip)
+    float *l1_wd = nullptr, *l1_bd = nullptr, *l1_wa = nullptr, *l1_ba = nullptr;
+    int l1_cx = 0, l1_cxp = 0;
 };
 
 struct Tensor { int id = -1; int B = 0, H = 0, W = 0, C = 0; };
@@ -249,6 +252,7 @@ struct ccvpe_handle_s {
     bool finalized = false;
     bool debug = false;
     bool autotune = true;
+    bool fuse_level1 = true;      // CCVPE_FUSE_L1=0 falls back to deconv / conv / tail launches
     int graph_mode = -1;          // -1 auto (plans of <= 4 samples replay a hipGraph), 0 never, 1 always
     hipStream_t capture_stream = nullptr;
     std::vector<void*> dev_allocs;
@@ -429,6 +433,30 @@ static int build_decoder(ccvpe_handle_s* h, DecoderW& d, const DecLevel* lv, con
             if ((rc = pack_conv(h, d.deconv[j], 4 * cout, 1, cin, cinp, cmap,
                                 [&](int nn, int, int c) { int qd = nn / cout, o = nn % cout; return w[((size_t)c * cout + o) * 4 + qd]; },
                                 bias, 1, 1))) return rc;
+        }
+        if (j == 5) {   // dedicated layouts for the fused last level
+            const auto& w = h->host["deconv" + n + sfx + ".weight"];
+            const auto& b = h->host["deconv" + n + sfx + ".bias"];
+            const int cin = lv[j].din, cout = lv[j].dout;   // cout == 16
+            const int nscore = every_level_scored ? 1 : 0;
+            const int spad = score_pad(nscore);
+            d.l1_cx = spad + (cin - nscore);
+            d.l1_cxp = round_up(d.l1_cx, 16);
+            std::vector<float> wd((size_t)64 * d.l1_cxp, 0.f);
+            for (int c = 0; c < cin; ++c) {
+                const int cm = c < nscore ? c : c - nscore + spad;
+                for (int o = 0; o < cout; ++o)
+                    for (int qd = 0; qd < 4; ++qd) wd[(size_t)(qd * 16 + o) * d.l1_cxp + cm] = w[((size_t)c * cout + o) * 4 + qd];
+            }
+            if ((rc = upload(h, wd, &d.l1_wd))) return rc;
+            if ((rc = upload(h, b, &d.l1_bd))) return rc;
+            const auto& wa = h->host["conv" + n + sfx + ".0.weight"];   // [16][16][3][3] -> [16][144], k = tap*16 + c
+            std::vector<float> pk(16 * 144);
+            for (int o = 0; o < 16; ++o)
+                for (int c = 0; c < 16; ++c)
+                    for (int t = 0; t < 9; ++t) pk[o * 144 + t * 16 + c] = wa[((size_t)o * 16 + c) * 9 + t];
+            if ((rc = upload(h, pk, &d.l1_wa))) return rc;
+            if ((rc = upload(h, h->host["conv" + n + sfx + ".0.bias"], &d.l1_ba))) return rc;
         }
         {
             const auto& w = h->host["conv" + n + sfx + ".0.weight"];
@@ -706,6 +734,25 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
         return o;
     };
 
+    // fused last level: deconv1 + conv1[0] + ReLU + conv1[2] (+ normalize) in one launch
+    auto plan_level1_fused = [&](const DecoderW& dw, Tensor din, int cin_real, int cout, bool is_ori, Tensor raw, const std::string& tag) {
+        Level1Params lp{};
+        lp.x_ld = din.C; lp.cx = dw.l1_cx; lp.cxp = dw.l1_cxp; lp.B = B; lp.H = CCVPE_OUT_HW; lp.W = CCVPE_OUT_HW;
+        lp.wd = dw.l1_wd; lp.bd = dw.l1_bd; lp.wa = dw.l1_wa; lp.ba = dw.l1_ba; lp.wt = dw.tail_w;
+        lp.bt[0] = dw.tail_b[0]; lp.bt[1] = dw.tail_b[1]; lp.cout = cout; lp.normalize = is_ori ? 1 : 0;
+        const bool has_raw = raw.id >= 0;
+        std::vector<Tensor> uses = {din};
+        if (has_raw) uses.push_back(raw);
+        const double px = (double)B * CCVPE_OUT_HW * CCVPE_OUT_HW;
+        pl.add(tag + ".fused", uses, [=](const Ctx& c) {
+            Level1Params q = lp;
+            q.x = c.ptr(din);
+            q.out = is_ori ? c.out.ori : c.out.logits_flattened;
+            q.raw = has_raw ? c.ptr(raw) : nullptr;
+            launch_level1(q, c.stream);
+        }, px / 4 * 2.0 * cin_real * 64 + px * 2.0 * 144 * 16 + px * 2.0 * 144 * cout, 4.0 * (px / 4 * lp.cx + px * cout));
+    };
+
     Tensor x = dmap;
     Tensor loc_mid;
     for (int k = 0; k < 6; ++k) {   // matching level k+1 feeds decoder level 6-k
@@ -746,11 +793,12 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
             launch_match(q, c.stream);
         }, 4.0 * B * hw * (double)R * L[k], 4.0 * B * hw * (2.0 * C + R + 8));
         pl.taps["loc_in" + std::to_string(6 - k)] = {lin, 0, lin.C};
+        if (k == 5 && h->fuse_level1) { plan_level1_fused(h->loc, lin, vs.loc[5].din, 1, false, Tensor{}, "loc1"); break; }
         Tensor o = plan_level(h->loc, vs.loc, k, lin, loc_cat[k], "loc" + std::to_string(6 - k));
         if (k < 5) { pl.taps["loc_level" + std::to_string(6 - k)] = {o, 0, o.C}; x = o; }
         else loc_mid = o;
     }
-    {
+    if (!h->fuse_level1) {
         Tensor m = loc_mid;
         const float* tw = h->loc.tail_w;
         const float tb = h->loc.tail_b[0];
@@ -760,6 +808,8 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
             p.normalize = 0; p.out = c.out.logits_flattened; p.raw = nullptr;
             launch_tail_conv(p, c.stream);
         }, 2.0 * B * 262144.0 * 144, 4.0 * B * 262144.0 * 17);
+    }
+    {
         Tensor part = pl.alloc(B, 1, 64, 2);
         pl.add("softmax", {part}, [=](const Ctx& c) {
             SoftmaxParams p{};
@@ -772,13 +822,16 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
     {
         Tensor xo = ori_in6;
         Tensor ori_mid;
+        Tensor raw;
+        if (h->debug) { raw = pl.alloc(B, 2, CCVPE_OUT_HW, CCVPE_OUT_HW); pl.taps["ori_level1_nchw"] = {raw, 0, -1}; }
+        bool fused_done = false;
         for (int j = 0; j < 6; ++j) {
+            if (j == 5 && h->fuse_level1) { plan_level1_fused(h->ori, xo, vs.ori[5].din, 2, true, raw, "ori1"); fused_done = true; break; }
             Tensor o = plan_level(h->ori, vs.ori, j, xo, ori_cat[j], "ori" + std::to_string(6 - j));
             if (j < 5) { pl.taps["ori_level" + std::to_string(6 - j)] = {o, 0, o.C}; xo = o; }
             else ori_mid = o;
         }
-        Tensor raw;
-        if (h->debug) { raw = pl.alloc(B, 2, CCVPE_OUT_HW, CCVPE_OUT_HW); pl.taps["ori_level1_nchw"] = {raw, 0, -1}; }
+        if (!fused_done) {
         Tensor m = ori_mid;
         const float* tw = h->ori.tail_w;
         const float tb0 = h->ori.tail_b[0], tb1 = h->ori.tail_b[1];
@@ -791,6 +844,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
             p.normalize = 1; p.out = c.out.ori; p.raw = dbg ? c.ptr(raw) : nullptr;
             launch_tail_conv(p, c.stream);
         }, 2.0 * B * 262144.0 * 288, 4.0 * B * 262144.0 * 18);
+        }
     }
     pl.assign();
     return 0;
@@ -822,6 +876,7 @@ int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
     h->vs = make_variant(cfg->variant);
     if (const char* e = getenv("CCVPE_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_GRAPH")) h->graph_mode = std::atoi(e) != 0;
+    if (const char* e = getenv("CCVPE_FUSE_L1")) h->fuse_level1 = std::atoi(e) != 0;
     const int n = (int)(cfg->ori_noise / 18.f);
     for (int k = 0; k < 6; ++k)
         h->rolls[k] = (cfg->variant == CCVPE_VARIANT_VIGOR_ORI_PRIOR && k > 0) ? 2 * n + 1 : h->vs.n_rolls;

@@ -157,6 +157,24 @@ struct TailConvParams {
 };
 void launch_tail_conv(const TailConvParams& p, hipStream_t s);
 
+// Fused last decoder level (kernels_level1.hip): deconv k2s2 (cx -> 16) + conv3x3 (16 -> 16) + ReLU +
+// conv3x3 (16 -> cout) [+ L2 normalise], NHWC input at H/2 x W/2, NCHW output at H x W.
+struct Level1Params {
+    const float* x;            // NHWC [B, H/2, W/2, x_ld], first cx channels used
+    int x_ld, cx, cxp;         // cxp = cx rounded up to 16 (weights zero padded)
+    int B, H, W;               // output geometry (512 x 512)
+    const float* wd;           // [64][cxp]  n = (dy*2+dx)*16 + o
+    const float* bd;           // [16]
+    const float* wa;           // [16][144]  k = (ky*3+kx)*16 + c
+    const float* ba;           // [16]
+    const float* wt;           // [9][16][cout]
+    float bt[2];
+    int cout, normalize;
+    float* out;                // NCHW [B, cout, H, W]
+    float* raw;                // optional un-normalised copy (debug tap)
+};
+void launch_level1(const Level1Params& p, hipStream_t s);
+
 struct SoftmaxParams {
     const float* logits;       // [B][n]
     int B, n;

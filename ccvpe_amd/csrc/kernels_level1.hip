@@ -1,0 +1,181 @@
+// Fused last decoder level:  ConvTranspose2d(k2,s2, CX->16) -> conv3x3(16->16)+ReLU -> conv3x3(16->{1,2})
+// (-> F.normalize for the orientation branch), writing the NCHW outputs directly.
+//
+// Reference: deconv1 / conv1 (models.py:422-425, 625-626) and deconv1_ori / conv1_ori + normalize
+// (models.py:443-446, 648-650); KITTI / Oxford copies at :727-728, :748-749, :1026-1028, :1046-1048.
+//
+// Unfused, this level moves three 512x512x16 fp32 tensors per sample through HBM and runs its 3x3 conv as
+// an N=16 GEMM with 5 K tiles (prologue/epilogue dominated).  Here one workgroup owns a 16x16 output
+// tile: the 10x10 input pixels it depends on are staged in LDS once, the transposed conv (a [100 x CX] x
+// [CX x 64] GEMM) and the 3x3 conv (a [324 x 144] x [144 x 16] GEMM whose A operand is gathered from the
+// LDS tile at 9 shifted positions) run on v_mfma_f32_16x16x4_f32, the final 16->{1,2} conv on the VALU,
+// and only the 1-2 output channels leave the chip.  Zero padding of both 3x3 convs is applied where the
+// reference applies it: intermediate pixels outside the 512x512 image are forced to 0 (not bias).
+#include "kernels.h"
+
+#include <algorithm>
+
+namespace ccvpe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int T = 16;          // output tile
+static constexpr int DT = T + 4;      // deconv-output tile (halo 2)
+static constexpr int AT = T + 2;      // conv_a-output tile (halo 1)
+static constexpr int XT = DT / 2;     // input tile (10 x 10)
+static constexpr int PS = 20;         // floats per pixel in the D / A tiles (16 + 4 pad: conflict-free b128)
+
+template <int COUT>
+__global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int CXP = p.cxp;                 // input channels padded to a multiple of 16
+    const int XS = CXP + 4;                // row stride of the X tile and of the deconv weights
+    float* Xs = smem;                      // [XT*XT][XS]
+    float* Wd = Xs + XT * XT * XS;         // [64][XS]   n = (dy*2+dx)*16 + o
+    const int r0f = max((XT * XT + 64) * XS, AT * AT * PS);   // region 0 must also hold the aliased A tile
+    float* Ds = smem + r0f;                // [DT*DT][PS]
+    float* As = smem;                      // [AT*AT][PS]  (aliases Xs/Wd, dead after the deconv stage)
+    float* Wt = Ds + DT * DT * PS;         // [9][16][COUT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int X0 = blockIdx.x * T, Y0 = blockIdx.y * T, b = blockIdx.z;
+    const int H = p.H, W = p.W;            // output size (512); input is H/2 x W/2
+    const int IH = H >> 1, IW = W >> 1;
+    const int xr0 = (Y0 >> 1) - 1, xc0 = (X0 >> 1) - 1;
+
+    // ---- stage 0: X tile, deconv weights, tail weights -> LDS ----
+    const int c4n = CXP >> 2;
+    for (int i = tid; i < XT * XT * c4n; i += 256) {
+        const int px = i / c4n, c4 = i - px * c4n;
+        const int xr = xr0 + px / XT, xc = xc0 + px % XT;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)xr < (unsigned)IH && (unsigned)xc < (unsigned)IW && c4 * 4 < p.cx)
+            v = *reinterpret_cast<const f32x4*>(p.x + (((size_t)b * IH + xr) * IW + xc) * p.x_ld + c4 * 4);
+        *reinterpret_cast<f32x4*>(Xs + px * XS + c4 * 4) = v;
+    }
+    for (int i = tid; i < 64 * c4n; i += 256) {
+        const int n = i / c4n, c4 = i - n * c4n;
+        *reinterpret_cast<f32x4*>(Wd + n * XS + c4 * 4) = *reinterpret_cast<const f32x4*>(p.wd + (size_t)n * CXP + c4 * 4);
+    }
+    for (int i = tid; i < 9 * 16 * COUT; i += 256) Wt[i] = p.wt[i];
+    // conv_a weights for this lane: B operand of MFMA j at tap t is Wa[n = lane&15][t*16 + 4*(lane>>4) + j]
+    f32x4 wa[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wa[t] = *reinterpret_cast<const f32x4*>(p.wa + (size_t)(lane & 15) * 144 + t * 16 + 4 * (lane >> 4));
+    const float bd = p.bd[lane & 15];
+    const float ba = p.ba[lane & 15];
+    __syncthreads();
+
+    // ---- stage 1: transposed conv as GEMM [100 x CXP] x [CXP x 64]; unit = (m-tile, (dy,dx)) ----
+    const int kch = CXP >> 4;
+    for (int u = wave; u < 7 * 4; u += 4) {
+        const int mt = u >> 2, nt = u & 3;
+        const int prow = min(mt * 16 + (lane & 15), XT * XT - 1);
+        const float* ap = Xs + prow * XS + 4 * (lane >> 4);
+        const float* bp = Wd + (nt * 16 + (lane & 15)) * XS + 4 * (lane >> 4);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < kch; ++kc) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 16);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(bp + kc * 16);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+        }
+        const int dy = nt >> 1, dx = nt & 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int px = mt * 16 + (lane >> 4) * 4 + r;       // X pixel of this accumulator row
+            if (px < XT * XT) {
+                const int dr = 2 * (px / XT) + dy, dc = 2 * (px % XT) + dx;          // position in the D tile
+                const int gy = Y0 - 2 + dr, gx = X0 - 2 + dc;                        // position in the image
+                const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                Ds[(dr * DT + dc) * PS + (lane & 15)] = in ? acc[r] + bd : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2: conv3x3 16->16 + ReLU on the 18x18 halo tile: 21 m-tiles of 16 pixels, 36 MFMAs each ----
+    for (int mt = wave; mt < (AT * AT + 15) / 16; mt += 4) {
+        const int pa = min(mt * 16 + (lane & 15), AT * AT - 1);
+        const int ay = pa / AT, ax = pa - ay * AT;
+        const float* dp = Ds + (ay * DT + ax) * PS + 4 * (lane >> 4);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(dp + ((t / 3) * DT + (t % 3)) * PS);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wa[t].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wa[t].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wa[t].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wa[t].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = mt * 16 + (lane >> 4) * 4 + r;
+            if (q < AT * AT) {
+                const int gy = Y0 - 1 + q / AT, gx = X0 - 1 + q % AT;
+                const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                As[q * PS + (lane & 15)] = in ? fmaxf(acc[r] + ba, 0.f) : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 3: conv3x3 16->COUT on the VALU, one output pixel per thread, NCHW store ----
+    const int oy = tid >> 4, ox = tid & 15;
+    float o[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) o[c] = p.bt[c];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float* ap = As + ((oy + t / 3) * AT + ox + t % 3) * PS;
+        const float* wp = Wt + t * 16 * COUT;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) o[c] = fmaf(v[e], wp[(c4 * 4 + e) * COUT + c], o[c]);
+        }
+    }
+    const size_t hw = (size_t)H * W;
+    const size_t opix = (size_t)(Y0 + oy) * W + X0 + ox;
+    if (p.raw) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) p.raw[((size_t)b * COUT + c) * hw + opix] = o[c];
+    }
+    if (p.normalize) {
+        float n2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) n2 = fmaf(o[c], o[c], n2);
+        const float inv = 1.f / fmaxf(sqrtf(n2), 1e-12f);
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) o[c] *= inv;
+    }
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) p.out[((size_t)b * COUT + c) * hw + opix] = o[c];
+}
+
+size_t level1_lds_bytes(int cxp, int cout) {
+    const int XS = cxp + 4;
+    const size_t r0f = std::max<size_t>((size_t)(XT * XT + 64) * XS, (size_t)AT * AT * PS);
+    return (r0f + (size_t)DT * DT * PS + 9 * 16 * cout) * sizeof(float);
+}
+
+void launch_level1(const Level1Params& p, hipStream_t s) {
+    const size_t lds = level1_lds_bytes(p.cxp, p.cout);
+    dim3 grid(p.W / T, p.H / T, p.B);
+    if (p.cout == 1) {
+        static size_t set1 = 0;
+        if (lds > set1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(level1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set1 = lds; }
+        hipLaunchKernelGGL(level1_kernel<1>, grid, dim3(256), lds, s, p);
+    } else {
+        static size_t set2 = 0;
+        if (lds > set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(level1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set2 = lds; }
+        hipLaunchKernelGGL(level1_kernel<2>, grid, dim3(256), lds, s, p);
+    }
+}
+
+}  // namespace ccvpe
