@@ -67,56 +67,84 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
     __syncthreads();
 
     // ---- stage 1: transposed conv as GEMM [100 x CXP] x [CXP x 64]; unit = (m-tile, (dy,dx)) ----
+    // two independent accumulator chains per wave (m-tiles mt and mt+4) hide the 40-cycle dependent-MFMA latency
     const int kch = CXP >> 4;
-    for (int u = wave; u < 7 * 4; u += 4) {
-        const int mt = u >> 2, nt = u & 3;
-        const int prow = min(mt * 16 + (lane & 15), XT * XT - 1);
-        const float* ap = Xs + prow * XS + 4 * (lane >> 4);
-        const float* bp = Wd + (nt * 16 + (lane & 15)) * XS + 4 * (lane >> 4);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int kc = 0; kc < kch; ++kc) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 16);
-            const f32x4 w = *reinterpret_cast<const f32x4*>(bp + kc * 16);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
-        }
+    {
+        const int nt = wave;                       // wave w owns output parity (dy,dx) = (w>>1, w&1)
         const int dy = nt >> 1, dx = nt & 1;
+        const float* bp = Wd + (nt * 16 + (lane & 15)) * XS + 4 * (lane >> 4);
+        for (int mt0 = 0; mt0 < 7; mt0 += 2) {
+            const int mt1 = mt0 + 1;               // may be 7 (invalid): computed on clamped rows, never stored
+            const float* ap0 = Xs + min(mt0 * 16 + (lane & 15), XT * XT - 1) * XS + 4 * (lane >> 4);
+            const float* ap1 = Xs + min(mt1 * 16 + (lane & 15), XT * XT - 1) * XS + 4 * (lane >> 4);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            for (int kc = 0; kc < kch; ++kc) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap0 + kc * 16);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap1 + kc * 16);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(bp + kc * 16);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w.w, acc1, 0, 0, 0);
+            }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int px = mt * 16 + (lane >> 4) * 4 + r;       // X pixel of this accumulator row
-            if (px < XT * XT) {
-                const int dr = 2 * (px / XT) + dy, dc = 2 * (px % XT) + dx;          // position in the D tile
-                const int gy = Y0 - 2 + dr, gx = X0 - 2 + dc;                        // position in the image
-                const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                Ds[(dr * DT + dc) * PS + (lane & 15)] = in ? acc[r] + bd : 0.f;
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int mt = h2 ? mt1 : mt0;
+                const f32x4 acc = h2 ? acc1 : acc0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int px = mt * 16 + (lane >> 4) * 4 + r;       // X pixel of this accumulator row
+                    if (px < XT * XT) {
+                        const int dr = 2 * (px / XT) + dy, dc = 2 * (px % XT) + dx;          // position in the D tile
+                        const int gy = Y0 - 2 + dr, gx = X0 - 2 + dc;                        // position in the image
+                        const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                        Ds[(dr * DT + dc) * PS + (lane & 15)] = in ? acc[r] + bd : 0.f;
+                    }
+                }
             }
         }
     }
     __syncthreads();
 
     // ---- stage 2: conv3x3 16->16 + ReLU on the 18x18 halo tile: 21 m-tiles of 16 pixels, 36 MFMAs each ----
-    for (int mt = wave; mt < (AT * AT + 15) / 16; mt += 4) {
-        const int pa = min(mt * 16 + (lane & 15), AT * AT - 1);
-        const int ay = pa / AT, ax = pa - ay * AT;
-        const float* dp = Ds + (ay * DT + ax) * PS + 4 * (lane >> 4);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NMT = (AT * AT + 15) / 16;   // 21
+    for (int mt0 = wave; mt0 < NMT; mt0 += 8) {
+        const int mt1 = mt0 + 4;                   // second chain (may be >= NMT: clamped reads, no stores)
+        const int pa0 = min(mt0 * 16 + (lane & 15), AT * AT - 1);
+        const int pa1 = min(mt1 * 16 + (lane & 15), AT * AT - 1);
+        const float* dp0 = Ds + ((pa0 / AT) * DT + pa0 % AT) * PS + 4 * (lane >> 4);
+        const float* dp1 = Ds + ((pa1 / AT) * DT + pa1 % AT) * PS + 4 * (lane >> 4);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(dp + ((t / 3) * DT + (t % 3)) * PS);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wa[t].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wa[t].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wa[t].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wa[t].w, acc, 0, 0, 0);
+            const int toff = ((t / 3) * DT + (t % 3)) * PS;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(dp0 + toff);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(dp1 + toff);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wa[t].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wa[t].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wa[t].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wa[t].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wa[t].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wa[t].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wa[t].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wa[t].w, acc1, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = mt * 16 + (lane >> 4) * 4 + r;
-            if (q < AT * AT) {
-                const int gy = Y0 - 1 + q / AT, gx = X0 - 1 + q % AT;
-                const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                As[q * PS + (lane & 15)] = in ? fmaxf(acc[r] + ba, 0.f) : 0.f;
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int mt = h2 ? mt1 : mt0;
+            const f32x4 acc = h2 ? acc1 : acc0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = mt * 16 + (lane >> 4) * 4 + r;
+                if (q < AT * AT) {
+                    const int gy = Y0 - 1 + q / AT, gx = X0 - 1 + q % AT;
+                    const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                    As[q * PS + (lane & 15)] = in ? fmaxf(acc[r] + ba, 0.f) : 0.f;
+                }
             }
         }
     }
