@@ -114,6 +114,7 @@ static int round_up(int a, int b) { return (a + b - 1) / b * b; }
 // ------------------------------------------------------------------------------------------------
 struct PackedConv {
     float* w = nullptr;
+    unsigned short *w_hi = nullptr, *w_lo = nullptr;   // bf16x3 planes (precision mode 1 only)
     float* bias = nullptr;
     int N = 0, Kpad = 0, nchunks = 0, cinp = 0, KH = 1, KW = 1;
 };
@@ -345,6 +346,26 @@ static int pack_conv(ccvpe_handle_s* h, PackedConv& pc, int N, int taps, int cin
     pc.N = N; pc.Kpad = kpad; pc.nchunks = K / 8; pc.cinp = cinp; pc.KH = KH; pc.KW = KW;
     int rc = upload(h, w, &pc.w);
     if (rc) return rc;
+    if (h->cfg.reserved[0] == 1) {   // bf16x3: hi = bf16(w), lo = bf16(w - hi), round to nearest even
+        auto to_bf16 = [](float f) -> unsigned short {
+            uint32_t u; std::memcpy(&u, &f, 4);
+            if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+            return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        };
+        std::vector<unsigned short> hi(w.size()), lo(w.size());
+        for (size_t i = 0; i < w.size(); ++i) {
+            hi[i] = to_bf16(w[i]);
+            uint32_t hu = (uint32_t)hi[i] << 16; float hf; std::memcpy(&hf, &hu, 4);
+            lo[i] = to_bf16(w[i] - hf);
+        }
+        for (int plane = 0; plane < 2; ++plane) {
+            void* d = nullptr;
+            HIPCHK(hipMalloc(&d, hi.size() * sizeof(unsigned short)));
+            h->dev_allocs.push_back(d);
+            HIPCHK(hipMemcpy(d, plane ? lo.data() : hi.data(), hi.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            (plane ? pc.w_lo : pc.w_hi) = (unsigned short*)d;
+        }
+    }
     return upload(h, bias, &pc.bias);
 }
 static std::vector<int> identity_map(int n) { std::vector<int> m(n); for (int i = 0; i < n; ++i) m[i] = i; return m; }
@@ -501,7 +522,7 @@ static ConvParams conv_params(const PackedConv& pc, const float* in, int in_ld, 
     ConvParams p{};
     p.in = in; p.in_ld = in_ld; p.B = B; p.H = H; p.W = W; p.Cin = pc.cinp; p.OH = OH; p.OW = OW;
     p.KH = pc.KH; p.KW = pc.KW; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
-    p.wpk = pc.w; p.Kpad = pc.Kpad; p.Npad = round_up(pc.N, conv_igemm_npad()); p.nchunks = pc.nchunks; p.bias = pc.bias; p.N = pc.N; p.act = act;
+    p.wpk = pc.w; p.w_hi = pc.w_hi; p.w_lo = pc.w_lo; p.Kpad = pc.Kpad; p.Npad = round_up(pc.N, conv_igemm_npad()); p.nchunks = pc.nchunks; p.bias = pc.bias; p.N = pc.N; p.act = act;
     p.gate = nullptr; p.resid = nullptr; p.resid_ld = 0; p.ndst = 0; p.mode = MODE_CONV; p.deconv_cout = 0;
     p.M = B * OH * OW;
     p.in_bytes = (unsigned)((size_t)B * H * W * in_ld * sizeof(float));
@@ -877,6 +898,8 @@ int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
     if (const char* e = getenv("CCVPE_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_GRAPH")) h->graph_mode = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_FUSE_L1")) h->fuse_level1 = std::atoi(e) != 0;
+    if (const char* e = getenv("CCVPE_PRECISION")) h->cfg.reserved[0] = (std::string(e) == "bf16x3") ? 1 : 0;
+    if (h->cfg.reserved[0] != 0 && h->cfg.reserved[0] != 1) { delete h; return fail(CCVPE_EINVAL, "unknown precision mode %d", cfg->reserved[0]); }
     const int n = (int)(cfg->ori_noise / 18.f);
     for (int k = 0; k < 6; ++k)
         h->rolls[k] = (cfg->variant == CCVPE_VARIANT_VIGOR_ORI_PRIOR && k > 0) ? 2 * n + 1 : h->vs.n_rolls;
@@ -999,6 +1022,7 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
         const int nkt = op.gemm_kpad / 32;
         for (int t = 1; t <= nt; ++t) {
             if (conv_igemm_tile_util(q, t) < 0.45) continue;
+            if (conv_igemm_tile_is_bf16x3(t) && h->cfg.reserved[0] != 1) continue;
             const long long blocks = conv_igemm_tile_blocks(q, t);
             for (int split = 1; split <= 16; split *= 2) {
                 if (split > 1) {   // split-K only where the grid underfills the chip and K is deep enough
@@ -1254,7 +1278,8 @@ int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Ci
     std::vector<float> hw(nw), hb(Cout, 0.f);
     HIPCHK(hipMemcpy(hw.data(), w, nw * sizeof(float), hipMemcpyDefault));
     if (bias) HIPCHK(hipMemcpy(hb.data(), bias, Cout * sizeof(float), hipMemcpyDefault));
-    ccvpe_handle_s tmp;   // only its dev_allocs list is used by the packer
+    ccvpe_handle_s tmp;   // only its dev_allocs list / precision flag are used by the packer
+    tmp.cfg.reserved[0] = 1;   // also pack the bf16x3 planes so every tile id can be exercised
     PackedConv pc;
     const int taps = KH * KW;
     int rc = pack_conv(&tmp, pc, Cout, taps, Cin, Cin, identity_map(Cin),

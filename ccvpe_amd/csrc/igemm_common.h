@@ -1,0 +1,60 @@
+// Device helpers shared by the fp32 and the bf16x3 implicit-GEMM kernels.
+#pragma once
+#include "kernels.h"
+
+namespace ccvpe {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int BK = 32;
+static constexpr int LDK = 36;  // floats per LDS row: 32 + 4 pad -> 144 B, (144/16)=9 odd => b128 reads conflict-free
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_SWISH) return v / (1.f + __expf(-v));
+    return v;
+}
+
+// Final placement of 4 consecutive output channels (n .. n+3) of GEMM row m: residual add, k2s2
+// pixel-shuffle addressing for the transposed conv, up to 3 concat destinations; 16-byte stores when legal.
+__device__ __forceinline__ void emit_out4(const ConvParams& p, int m, int n, f32x4 v) {
+    int opix = m, o = n;
+    if (p.mode == MODE_DECONV) {
+        const int q = n / p.deconv_cout;
+        o = n - q * p.deconv_cout;
+        const int x = m % p.W;
+        const int t = m / p.W;
+        const int y = t % p.H;
+        const int b = t / p.H;
+        opix = (b * 2 * p.H + 2 * y + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
+    }
+    if (p.vec_epi) {
+        if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.resid_ld + n);
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < p.ndst) *reinterpret_cast<f32x4*>(p.dst[d].ptr + (size_t)opix * p.dst[d].ld + p.dst[d].coff + o) = v;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n + e >= p.N) break;
+            float ve = v[e];
+            int oe = o + e, pe = opix;
+            if (p.mode == MODE_DECONV) {   // a float4 may straddle two (dy,dx) groups when cout % 4 != 0
+                const int q = (n + e) / p.deconv_cout;
+                oe = (n + e) - q * p.deconv_cout;
+                const int x = m % p.W;
+                const int t = m / p.W;
+                pe = ((t / p.H) * 2 * p.H + 2 * (t % p.H) + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
+            } else if (p.resid) {
+                ve += p.resid[(size_t)m * p.resid_ld + n + e];
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                if (d < p.ndst) p.dst[d].ptr[(size_t)pe * p.dst[d].ld + p.dst[d].coff + oe] = ve;
+        }
+    }
+}
+
+}  // namespace ccvpe

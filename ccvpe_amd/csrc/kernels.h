@@ -29,6 +29,8 @@ struct ConvParams {
     int OH, OW;                // GEMM-row geometry (conv: output map; deconv: == H, W)
     int KH, KW, stride, pad_t, pad_l;
     const float* wpk;          // [Npad][Kpad], k contiguous
+    const unsigned short* w_hi;   // bf16x3 mode: bf16(w) and bf16(w - hi), same [Npad][Kpad] layout (null = unavailable)
+    const unsigned short* w_lo;
     int Kpad;                  // multiple of 32
     int Npad;                  // rows in wpk (multiple of conv_igemm_npad())
     int nchunks;               // KH*KW*Cin/8 valid 8-channel chunks
@@ -61,6 +63,11 @@ long long conv_igemm_tile_blocks(const ConvParams& p, int tile);
 int conv_igemm_prepare(ConvParams& p);
 int launch_conv_igemm(const ConvParams& p, int tile, hipStream_t s);   // 0, or -1 for unsupported geometry
 int conv_igemm_npad();       // row padding of packed weights (multiple every tile divides)
+bool conv_igemm_tile_is_bf16x3(int tile);
+void launch_splitk_reduce(const ConvParams& p, hipStream_t s);
+struct Bf16x3Tile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); };
+int bf16x3_num_tiles();
+const Bf16x3Tile* bf16x3_tile(int i);
 int conv_igemm_last_tile();  // tile id of the most recent launch on this thread (then reset to 0)
 const char* conv_igemm_tile_name(int tile);
 

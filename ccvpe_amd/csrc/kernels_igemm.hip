@@ -16,24 +16,11 @@
 // fmaf chain) at 64 FLOP/clk/SIMD; the 16x16 form serves narrow outputs (N = 16, 40, 80 ...) where a
 // 32-wide tile would waste matrix-core cycles on padding.  One ds_read_b128 per operand feeds four
 // MFMAs: lane l holds k = 4*(l / MT) + j of its row for j = 0..3, the same k permutation on A and B.
-#include "kernels.h"
+#include "igemm_common.h"
 
 #include <algorithm>
 
 namespace ccvpe {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-static constexpr int BK = 32;
-static constexpr int LDK = 36;  // floats per LDS row: 32 + 4 pad -> 144 B, (144/16)=9 odd => b128 reads conflict-free
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == ACT_RELU) return fmaxf(v, 0.f);
-    if (act == ACT_SWISH) return v / (1.f + __expf(-v));
-    return v;
-}
 
 template <int MT> struct Mfma;
 template <> struct Mfma<32> {
@@ -48,46 +35,6 @@ template <> struct Mfma<16> {
     static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ int row(int r, int lane) { return (lane >> 4) * 4 + r; }
 };
-
-// Final placement of 4 consecutive output channels (n .. n+3) of GEMM row m: residual add, k2s2
-// pixel-shuffle addressing for the transposed conv, up to 3 concat destinations; 16-byte stores when legal.
-__device__ __forceinline__ void emit_out4(const ConvParams& p, int m, int n, f32x4 v) {
-    int opix = m, o = n;
-    if (p.mode == MODE_DECONV) {
-        const int q = n / p.deconv_cout;
-        o = n - q * p.deconv_cout;
-        const int x = m % p.W;
-        const int t = m / p.W;
-        const int y = t % p.H;
-        const int b = t / p.H;
-        opix = (b * 2 * p.H + 2 * y + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
-    }
-    if (p.vec_epi) {
-        if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.resid_ld + n);
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-            if (d < p.ndst) *reinterpret_cast<f32x4*>(p.dst[d].ptr + (size_t)opix * p.dst[d].ld + p.dst[d].coff + o) = v;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (n + e >= p.N) break;
-            float ve = v[e];
-            int oe = o + e, pe = opix;
-            if (p.mode == MODE_DECONV) {   // a float4 may straddle two (dy,dx) groups when cout % 4 != 0
-                const int q = (n + e) / p.deconv_cout;
-                oe = (n + e) - q * p.deconv_cout;
-                const int x = m % p.W;
-                const int t = m / p.W;
-                pe = ((t / p.H) * 2 * p.H + 2 * (t % p.H) + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
-            } else if (p.resid) {
-                ve += p.resid[(size_t)m * p.resid_ld + n + e];
-            }
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-                if (d < p.ndst) p.dst[d].ptr[(size_t)pe * p.dst[d].ld + p.dst[d].coff + oe] = ve;
-        }
-    }
-}
 
 template <int BM, int BN, int WGM, int WGN, int MT, bool GATE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
@@ -310,6 +257,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
     }
 }
 
+void launch_splitk_reduce(const ConvParams& p, hipStream_t s) {
+    const long long total = (long long)p.M * ((p.N + 3) / 4);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+}
+
 template <int BM, int BN, int WGM, int WGN, int MT, bool GATE>
 static void launch_cfg2(const ConvParams& p, hipStream_t s) {
     constexpr size_t lds = 2 * (BM + BN) * LDK * sizeof(float);
@@ -321,11 +274,7 @@ static void launch_cfg2(const ConvParams& p, hipStream_t s) {
     }
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.splitk > 1 ? p.splitk : 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
-    if (p.splitk > 1) {
-        const long long total = (long long)p.M * ((p.N + 3) / 4);
-        const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
-    }
+    if (p.splitk > 1) launch_splitk_reduce(p, s);
 }
 
 template <int BM, int BN, int WGM, int WGN, int MT>
@@ -360,20 +309,28 @@ static const TileCfg TILES[] = {
 static constexpr int NTILES = (int)(sizeof(TILES) / sizeof(TILES[0]));
 
 int conv_igemm_npad() { return 128; }
-int conv_igemm_num_tiles() { return NTILES; }
+int conv_igemm_num_tiles() { return NTILES + bf16x3_num_tiles(); }
+bool conv_igemm_tile_is_bf16x3(int tile) { tile &= 0xff; return tile > NTILES && tile <= NTILES + bf16x3_num_tiles(); }
+static void tile_dims(int tile, int& bm, int& bn) {
+    if (tile >= 1 && tile <= NTILES) { bm = TILES[tile - 1].bm; bn = TILES[tile - 1].bn; }
+    else if (conv_igemm_tile_is_bf16x3(tile)) { bm = (*bf16x3_tile(tile - NTILES - 1)).bm; bn = (*bf16x3_tile(tile - NTILES - 1)).bn; }
+    else { bm = bn = 0; }
+}
 
 // fraction of the launched MFMA work that is useful (padding of M and N to the tile)
 double conv_igemm_tile_util(const ConvParams& p, int tile) {
-    if (tile < 1 || tile > NTILES) return 0.0;
-    const TileCfg& c = TILES[tile - 1];
-    double gm = (p.M + c.bm - 1) / c.bm, gn = (p.N + c.bn - 1) / c.bn;
-    return ((double)p.M * p.N) / (gm * c.bm * gn * c.bn);
+    int bm, bn;
+    tile_dims(tile, bm, bn);
+    if (!bm) return 0.0;
+    double gm = (p.M + bm - 1) / bm, gn = (p.N + bn - 1) / bn;
+    return ((double)p.M * p.N) / (gm * bm * gn * bn);
 }
 
 long long conv_igemm_tile_blocks(const ConvParams& p, int tile) {
-    if (tile < 1 || tile > NTILES) return 0;
-    const TileCfg& c = TILES[tile - 1];
-    return (long long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
+    int bm, bn;
+    tile_dims(tile, bm, bn);
+    if (!bm) return 0;
+    return (long long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
 }
 
 static int pick_tile(const ConvParams& p) {
@@ -395,7 +352,12 @@ static int pick_tile(const ConvParams& p) {
 
 static thread_local int g_last_tile = 0;
 int conv_igemm_last_tile() { int t = g_last_tile; g_last_tile = 0; return t; }
-const char* conv_igemm_tile_name(int tile) { tile &= 0xff; return (tile >= 1 && tile <= NTILES) ? TILES[tile - 1].name : ""; }
+const char* conv_igemm_tile_name(int tile) {
+    tile &= 0xff;
+    if (tile >= 1 && tile <= NTILES) return TILES[tile - 1].name;
+    if (conv_igemm_tile_is_bf16x3(tile)) return (*bf16x3_tile(tile - NTILES - 1)).name;
+    return "";
+}
 
 // exact small-range division by multiplication: q = (g * mul) >> 20 for 0 <= g < limit
 static int find_div_mul(int d, int limit) {
@@ -430,11 +392,13 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
     for (int d = 0; d < p.ndst; ++d) p.vec_epi = p.vec_epi && p.dst[d].ld % 4 == 0 && p.dst[d].coff % 4 == 0;
     int splitk = (tile >> 8) & 0xff;
     tile &= 0xff;
-    if (tile < 1 || tile > NTILES) tile = pick_tile(p);
+    if (conv_igemm_tile_is_bf16x3(tile) && (p.w_hi == nullptr || p.w_lo == nullptr)) tile = 0;   // planes not packed: fp32 path
+    if (tile < 1 || tile > NTILES + bf16x3_num_tiles()) tile = pick_tile(p);
     if (splitk < 2 || p.partial == nullptr || (size_t)splitk * p.M * p.N > p.partial_floats) splitk = 1;
     p.splitk = splitk;
     g_last_tile = tile | (splitk << 8);
-    TILES[tile - 1].launch(p, s);
+    if (tile <= NTILES) TILES[tile - 1].launch(p, s);
+    else (*bf16x3_tile(tile - NTILES - 1)).launch(p, s);
     return 0;
 }
 

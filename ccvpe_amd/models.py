@@ -74,13 +74,16 @@ class _CVMBase(nn.Module):
     _variant: str = ""
 
     def __init__(self, device, circular_padding: bool = False, ori_noise: Optional[float] = None,
-                 micro_batch: int = 0):
+                 micro_batch: int = 0, precision: str = "fp32"):
         super().__init__()
         v = spec.VARIANTS[self._variant]
         self.device = device
         self.circular_padding = bool(circular_padding)
         self.ori_noise = ori_noise
         self._micro_batch = int(micro_batch)
+        if precision not in ("fp32", "bf16x3"):
+            raise ValueError("precision must be 'fp32' (exact fp32 MFMA) or 'bf16x3' (3-term bf16 split, ~1e-5 relative)")
+        self._precision = precision
 
         self.grd_efficientnet = _EfficientNetParams()
         for lvl, c in enumerate(v.head_ch, 1):
@@ -140,6 +143,7 @@ class _CVMBase(nn.Module):
             cfg.ori_noise = float(self.ori_noise) if self.ori_noise is not None else 0.0
             cfg.device = index
             cfg.micro_batch = self._micro_batch
+            cfg.reserved[0] = 1 if self._precision == "bf16x3" else 0
             h = C.c_void_p()
             _lib.check(lib.ccvpe_create(C.byref(cfg), C.byref(h)), "ccvpe_create")
             self._handle, self._handle_device = h, index

@@ -60,7 +60,9 @@ typedef struct ccvpe_config {
     float   ori_noise;          /* variant 1 only: rolls i = -n..n, n = int(ori_noise/18) (models.py:489) */
     int32_t device;             /* HIP device ordinal */
     int32_t micro_batch;        /* samples per internal pass (0 = library default); larger batches loop */
-    int32_t reserved[3];
+    int32_t reserved[3];        /* reserved[0] = precision mode of the dense contractions:
+                                   0 exact fp32 MFMA (default); 1 "bf16x3": fp32 operands split into two bf16,
+                                   three bf16 MFMAs per product, fp32 accumulate (~2^-16 relative per term) */
 } ccvpe_config;
 
 /* Caller-allocated outputs of one forward call (device memory, NCHW contiguous, batch-major).

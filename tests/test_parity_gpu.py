@@ -17,16 +17,17 @@ CONTRACT_RTOL = 1e-3
 RTOL = 1e-4
 
 
-def build_model(cfg, micro_batch=0):
+def build_model(cfg, micro_batch=0, precision="fp32"):
     v = cfg["variant"]
+    kw = dict(micro_batch=micro_batch, precision=precision)
     if v == "vigor":
-        m = models.CVM_VIGOR("cuda", cfg["circular"], micro_batch=micro_batch)
+        m = models.CVM_VIGOR("cuda", cfg["circular"], **kw)
     elif v == "vigor_ori_prior":
-        m = models.CVM_VIGOR_ori_prior("cuda", cfg["ori_noise"], cfg["circular"], micro_batch=micro_batch)
+        m = models.CVM_VIGOR_ori_prior("cuda", cfg["ori_noise"], cfg["circular"], **kw)
     elif v == "kitti":
-        m = models.CVM_KITTI("cuda", micro_batch=micro_batch)
+        m = models.CVM_KITTI("cuda", **kw)
     else:
-        m = models.CVM_OxfordRobotCar("cuda", micro_batch=micro_batch)
+        m = models.CVM_OxfordRobotCar("cuda", **kw)
     m.load_state_dict(weights.generate_state_dict(v, cfg["seed"]))
     return m.to("cuda").eval()
 
@@ -168,3 +169,18 @@ def test_reload_state_dict_changes_result():
     c = m(g, s)[0]
     # re-ingesting the weights re-tunes the per-layer tiles, which may change the summation order
     assert (a - c).abs().max().item() <= 2e-5 * a.abs().max().item()
+
+
+@pytest.mark.parametrize("name", ["vigor_prior180_circ", "kitti", "oxford"])
+def test_bf16x3_mode_stays_inside_the_contract(name):
+    """Opt-in precision mode: fp32 operands split into two bf16, three bf16 MFMAs per product.  Expected error
+    ~1e-5 of each tensor's scale; asserted at 5e-4 (half the 1e-3 contract)."""
+    cfg = gu.CONFIGS[name]
+    fx = gu.load(name)
+    m = build_model(cfg, precision="bf16x3")
+    g, s = inputs(cfg)
+    outs = m(g, s)
+    worst = check_against_fixture(fx, outs, 5e-4)
+    assert worst <= CONTRACT_RTOL
+    post = m.postprocess(outs[1], outs[2])
+    assert np.array_equal(post["index"].cpu().numpy(), fx["post/index"])
