@@ -11,6 +11,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 static constexpr int BK = 32;
 static constexpr int LDK = 36;  // floats per LDS row: 32 + 4 pad -> 144 B, (144/16)=9 odd => b128 reads conflict-free
 
+// XCD-aware M-tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), so
+// give each XCD a contiguous run of M tiles - neighbouring output rows re-read the same input rows (3x3 halo)
+// and then hit the same L2.  Bijective for any grid size; placement only affects speed, never results.
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACT_SWISH) return v / (1.f + __expf(-v));

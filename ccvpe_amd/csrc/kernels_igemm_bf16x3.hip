@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.x * BM;
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
     const int n0 = blockIdx.y * BN;
     const int kq = tid & 7;
     const int r0 = tid >> 3;
