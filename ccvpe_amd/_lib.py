@@ -40,6 +40,12 @@ SYMBOLS = [
     ("ccvpe_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                 C.POINTER(Outputs), C.c_void_p]),
     ("ccvpe_postprocess", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("ccvpe_aerial_cache_bytes", C.c_size_t, [C.c_void_p, C.c_int32]),
+    ("ccvpe_encode_aerial", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("ccvpe_forward_cached", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.POINTER(Outputs), C.c_void_p]),
+    ("ccvpe_preprocess", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                   C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.c_void_p, C.c_void_p]),
     ("ccvpe_set_debug", C.c_int, [C.c_void_p, C.c_int32]),
     ("ccvpe_read_tap", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                  C.POINTER(C.c_int32 * 4)]),
@@ -53,6 +59,32 @@ SYMBOLS = [
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_void_p]),
 ]
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)   # train_VIGOR.py:60
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def preprocess(img_u8_hwc, shift=None, crop_w=None, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """uint8 [B,H,W,3] cuda tensor -> float32 NCHW [B,3,H,crop_w] (ToTensor + Normalize + roll + FoV crop)."""
+    import torch
+    lib = load()
+    assert img_u8_hwc.is_cuda and img_u8_hwc.dtype == torch.uint8 and img_u8_hwc.dim() == 4 and img_u8_hwc.shape[3] == 3
+    img = img_u8_hwc.contiguous()
+    B, H, W, _ = img.shape
+    crop_w = W if crop_w is None else int(crop_w)
+    out = torch.empty((B, 3, H, crop_w), dtype=torch.float32, device=img.device)
+    sh = None
+    if shift is not None:
+        sh = torch.as_tensor(shift, dtype=torch.int32, device=img.device).contiguous()
+        assert sh.numel() == B
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    stream = torch.cuda.current_stream(img.device).cuda_stream
+    rc = lib.ccvpe_preprocess(C.c_void_p(img.data_ptr()), B, H, W, C.c_void_p(sh.data_ptr()) if sh is not None else None,
+                              crop_w, C.byref(m), C.byref(s), C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+    check(rc, "ccvpe_preprocess")
+    return out
 
 
 def op_conv2d(x_nhwc, w, bias=None, stride=1, pad=0, act=0, tile=0, iters=0):

@@ -148,6 +148,8 @@ struct Ctx {
     ccvpe_outputs out{};
     float* splitk_scratch = nullptr;
     size_t splitk_floats = 0;
+    const float* cache_in = nullptr;   // aerial cache consumed by a "cached" plan
+    float* cache_out = nullptr;        // aerial cache produced by an "encode" plan
     float* ptr(const Tensor& t) const { return arena + (*off)[t.id]; }
     void launch_conv(ConvParams& p, int cfg) const {
         p.partial = splitk_scratch;
@@ -170,6 +172,7 @@ struct TapInfo { Tensor t; int coff; int C; };
 
 struct Plan {
     int B = 0, gh = 0, gw = 0;
+    int mode = 0;                 // 0 full forward, 1 aerial encode only, 2 forward from a cached aerial encoding
     bool debug = false;
     std::vector<size_t> size;     // floats per tensor
     std::vector<size_t> off;      // float offset in the arena
@@ -632,11 +635,28 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
     pl.taps[tag + "_volume"] = {vol, 0, 1280};
 }
 
-static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
+// Aerial cache: everything the decoders need from the aerial image, NHWC fp32, batch-major:
+// [descriptor map B x 8x8 x D | block15 B x 16^2 x 320 | block10 B x 32^2 x 112 | block4 B x 64^2 x 40 |
+//  block2 B x 128^2 x 24 | block0 B x 256^2 x 16]
+static const int TAP_HW[5] = {256, 1024, 4096, 16384, 65536};
+static const int TAP_C[5] = {320, 112, 40, 24, 16};
+static size_t cache_layout(const VariantSpec& vs, int B, size_t off[6]) {
+    size_t o = 0;
+    off[0] = o; o += (size_t)B * 64 * vs.sat_desc;
+    for (int t = 0; t < 5; ++t) { off[t + 1] = o; o += (size_t)B * TAP_HW[t] * TAP_C[t]; }
+    return o;
+}
+
+static int build_aerial_plan(ccvpe_handle_s* h, Plan& pl, int B);
+
+static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode = 0) {
+    if (mode == 1) return build_aerial_plan(h, pl, B);
+    const bool cached = mode == 2;
+    pl.mode = mode;
     const VariantSpec& vs = h->vs;
     pl.B = B; pl.gh = gh; pl.gw = gw; pl.debug = h->debug;
     pl.scratch = pl.alloc(1, 1, 1, (int)Plan::SPLITK_FLOATS);
-    pl.use_graph = h->graph_mode == 1 || (h->graph_mode < 0 && B <= 4);
+    pl.use_graph = !cached && (h->graph_mode == 1 || (h->graph_mode < 0 && B <= 4));
     if (pl.use_graph) {
         pl.io_grd = pl.alloc(B, 3, gh, gw);
         pl.io_sat = pl.alloc(B, 3, CCVPE_SAT_HW, CCVPE_SAT_HW);
@@ -681,7 +701,22 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
         td[t].t[0] = loc_cat[t]; td[t].coff[0] = vs.loc[t].dout;
         td[t].t[1] = ori_cat[t]; td[t].coff[1] = vs.ori[t].dout;
     }
-    plan_encoder(h, pl, h->sat_enc, false, B, CCVPE_SAT_HW, CCVPE_SAT_HW, false, td, senc, "sat");
+    size_t coff[6];
+    cache_layout(vs, B, coff);
+    if (!cached) {
+        plan_encoder(h, pl, h->sat_enc, false, B, CCVPE_SAT_HW, CCVPE_SAT_HW, false, td, senc, "sat");
+    } else {
+        for (int t = 0; t < 5; ++t) {   // cached encoder taps -> skip halves of the decoder concat buffers
+            Tensor lc = loc_cat[t], oc = ori_cat[t];
+            const int lcoff = vs.loc[t].dout, ocoff = vs.ori[t].dout;
+            const size_t src_off = coff[t + 1];
+            const int C = TAP_C[t];
+            const long long P = (long long)B * TAP_HW[t];
+            pl.add("sat.cached_tap" + std::to_string(TAP_BLOCK[t]), {lc, oc}, [=](const Ctx& c) {
+                launch_scatter_channels(c.cache_in + src_off, C, P, Dst{c.ptr(lc), lc.C, lcoff}, Dst{c.ptr(oc), oc.C, ocoff}, 2, c.stream);
+            }, 0, 4.0 * P * C * 3);
+        }
+    }
 
     // ---- ground descriptors ----
     int ntot = 0, ltot = 0, hoff[6], loff[6];
@@ -708,7 +743,14 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
 
     // ---- aerial descriptor map: conv k2 s2 over the 1280x16x16 volume ----
     Tensor dmap = pl.alloc(B, 8, 8, D);
-    {
+    if (cached) {
+        Tensor dm = dmap;
+        const long long P = (long long)B * 64;
+        pl.add("sat.cached_descmap", {dm}, [=](const Ctx& c) {
+            launch_scatter_channels(c.cache_in, D, P, Dst{c.ptr(dm), D, 0}, Dst{nullptr, 0, 0}, 1, c.stream);
+        }, 0, 8.0 * P * D);
+        pl.taps["sat_descriptor_map"] = {dmap, 0, D};
+    } else {
         const PackedConv* pc = &h->sat_desc;
         Tensor x = senc.vol;
         pl.add_conv("sat.descmap", {x, dmap}, B * 8 * 8, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
@@ -870,6 +912,37 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw) {
     pl.assign();
     return 0;
 }
+
+static int build_aerial_plan(ccvpe_handle_s* h, Plan& pl, int B) {
+    const VariantSpec& vs = h->vs;
+    pl.B = B; pl.gh = 0; pl.gw = 0; pl.mode = 1; pl.debug = false;
+    pl.scratch = pl.alloc(1, 1, 1, (int)Plan::SPLITK_FLOATS);
+    EncOut senc;
+    plan_encoder(h, pl, h->sat_enc, false, B, CCVPE_SAT_HW, CCVPE_SAT_HW, false, nullptr, senc, "sat");
+    size_t coff[6];
+    cache_layout(vs, B, coff);
+    const int D = vs.sat_desc;
+    {
+        const PackedConv* pc = &h->sat_desc;
+        Tensor x = senc.vol;
+        pl.add_conv("sat.descmap", {x}, B * 8 * 8, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
+            ConvParams p = conv_params(*pc, c.ptr(x), 1280, B, 16, 16, 8, 8, 2, 0, 0, ACT_NONE);
+            p.dst[0] = {c.cache_out, D, 0}; p.ndst = 1;
+            c.launch_conv(p, tile);
+        }, 2.0 * B * 64 * 5120.0 * D, 4.0 * (B * 256 * 1280.0 + 5120.0 * D));
+    }
+    for (int t = 0; t < 5; ++t) {
+        Tensor tp = senc.tap[TAP_BLOCK[t]];
+        const size_t o = coff[t + 1];
+        const size_t n = (size_t)B * TAP_HW[t] * TAP_C[t];
+        pl.add("sat.tap_to_cache" + std::to_string(TAP_BLOCK[t]), {tp}, [=](const Ctx& c) {
+            (void)hipMemcpyAsync(c.cache_out + o, c.ptr(tp), n * sizeof(float), hipMemcpyDeviceToDevice, c.stream);
+        }, 0, 8.0 * n);
+    }
+    pl.assign();
+    return 0;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
@@ -1051,11 +1124,11 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
     return 0;
 }
 
-static int get_plan(ccvpe_handle h, int B, int gh, int gw, Plan** out) {
+static int get_plan(ccvpe_handle h, int B, int gh, int gw, Plan** out, int mode = 0) {
     for (auto& p : h->plans)
-        if (p->B == B && p->gh == gh && p->gw == gw && p->debug == h->debug) { *out = p.get(); return 0; }
+        if (p->B == B && p->gh == gh && p->gw == gw && p->mode == mode && (mode == 1 || p->debug == h->debug)) { *out = p.get(); return 0; }
     auto pl = std::make_unique<Plan>();
-    int rc = build_plan(h, *pl, B, gh, gw);
+    int rc = build_plan(h, *pl, B, gh, gw, mode);
     if (rc) return rc;
     if (pl->total > h->arena_floats) {
         // growing the arena is the only synchronising step; it happens on the first call per shape
@@ -1088,8 +1161,10 @@ size_t ccvpe_workspace_bytes(ccvpe_handle h, int32_t batch, int32_t grd_h, int32
 }
 
 static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const float* sat, int batch,
-                       const ccvpe_outputs* out, hipStream_t stream, bool profile) {
-    if (!h || !grd || !sat || !out) return fail(CCVPE_EINVAL, "null argument");
+                       const ccvpe_outputs* out, hipStream_t stream, bool profile, const float* cache = nullptr) {
+    const int mode = cache ? 2 : 0;
+    if (!h || !grd || (!sat && !cache) || !out) return fail(CCVPE_EINVAL, "null argument");
+    if (cache && batch > h->cfg.micro_batch) return fail(CCVPE_EINVAL, "cached forward needs batch <= micro_batch (%d)", h->cfg.micro_batch);
     if (!h->finalized) return fail(CCVPE_ESTATE, "ccvpe_finalize_weights has not been called");
     if (batch <= 0) return fail(CCVPE_EINVAL, "batch must be positive");
     if (!out->logits_flattened || !out->heatmap || !out->ori) return fail(CCVPE_EINVAL, "null output buffer");
@@ -1100,20 +1175,21 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
     // make sure every plan (and the largest arena) exists before the first launch
     for (int done = 0; done < batch;) {
         const int mb = std::min(mbmax, batch - done);
-        Plan* pl; int rc = get_plan(h, mb, gh, gw, &pl);
+        Plan* pl; int rc = get_plan(h, mb, gh, gw, &pl, mode);
         if (rc) return rc;
         done += mb;
     }
     const size_t npx = (size_t)CCVPE_OUT_HW * CCVPE_OUT_HW;
     for (int done = 0; done < batch;) {
         const int mb = std::min(mbmax, batch - done);
-        Plan* pl; int rc = get_plan(h, mb, gh, gw, &pl);
+        Plan* pl; int rc = get_plan(h, mb, gh, gw, &pl, mode);
         if (rc) return rc;
         Ctx c;
+        c.cache_in = cache;
         c.arena = h->arena; c.off = &pl->off; c.stream = stream;
         c.splitk_scratch = c.ptr(pl->scratch); c.splitk_floats = Plan::SPLITK_FLOATS;
         c.grd = grd + (size_t)done * 3 * gh * gw;
-        c.sat = sat + (size_t)done * 3 * CCVPE_SAT_HW * CCVPE_SAT_HW;
+        c.sat = sat ? sat + (size_t)done * 3 * CCVPE_SAT_HW * CCVPE_SAT_HW : nullptr;
         c.out.logits_flattened = out->logits_flattened + done * npx;
         c.out.heatmap = out->heatmap + done * npx;
         c.out.ori = out->ori + done * 2 * npx;
@@ -1258,6 +1334,48 @@ int ccvpe_read_tap(ccvpe_handle h, const char* name, float* host_dst, size_t cap
     if (e != hipSuccess) return fail(CCVPE_EHIP, "tap copy failed: %s", hipGetErrorString(e));
     if (n_out) *n_out = n;
     if (shape_out) { shape_out[0] = t.B; shape_out[1] = ti.C; shape_out[2] = t.H; shape_out[3] = t.W; }
+    return 0;
+}
+
+size_t ccvpe_aerial_cache_bytes(ccvpe_handle h, int32_t batch) {
+    if (!h || batch <= 0) { fail(CCVPE_EINVAL, "bad argument"); return 0; }
+    size_t off[6];
+    return cache_layout(h->vs, batch, off) * sizeof(float);
+}
+
+int ccvpe_encode_aerial(ccvpe_handle h, const float* sat, int32_t batch, void* cache, void* stream) {
+    if (!h || !sat || !cache || batch <= 0) return fail(CCVPE_EINVAL, "bad argument");
+    if (!h->finalized) return fail(CCVPE_ESTATE, "ccvpe_finalize_weights has not been called");
+    if (batch > h->cfg.micro_batch) return fail(CCVPE_EINVAL, "aerial encode needs batch <= micro_batch (%d)", h->cfg.micro_batch);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    Plan* pl; int rc = get_plan(h, batch, 0, 0, &pl, 1);
+    if (rc) return rc;
+    Ctx c;
+    c.arena = h->arena; c.off = &pl->off; c.stream = (hipStream_t)stream;
+    c.splitk_scratch = c.ptr(pl->scratch); c.splitk_floats = Plan::SPLITK_FLOATS;
+    c.sat = sat; c.cache_out = (float*)cache;
+    for (auto& op : pl->ops) op.fn(c);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CCVPE_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int ccvpe_forward_cached(ccvpe_handle h, const float* grd, int32_t grd_h, int32_t grd_w, const void* cache, int32_t batch,
+                         const ccvpe_outputs* out, void* stream) {
+    if (!cache) return fail(CCVPE_EINVAL, "null cache");
+    return run_forward(h, grd, grd_h, grd_w, nullptr, batch, out, (hipStream_t)stream, false, (const float*)cache);
+}
+
+int ccvpe_preprocess(const uint8_t* hwc, int32_t batch, int32_t H, int32_t W, const int32_t* shift, int32_t crop_w,
+                     const float mean[3], const float stdv[3], float* out_nchw, void* stream) {
+    if (!hwc || !out_nchw || !mean || !stdv) return fail(CCVPE_EINVAL, "null argument");
+    if (batch <= 0 || H <= 0 || W <= 0 || crop_w <= 0 || crop_w > W) return fail(CCVPE_EINVAL, "bad geometry");
+    PreprocParams p{};
+    p.in = hwc; p.B = batch; p.H = H; p.W = W; p.crop_w = crop_w; p.shift = shift; p.out = out_nchw;
+    for (int c = 0; c < 3; ++c) { p.mean[c] = mean[c]; p.stdv[c] = stdv[c]; }
+    launch_preprocess(p, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CCVPE_EHIP, "preprocess launch failed: %s", hipGetErrorString(e));
     return 0;
 }
 

@@ -191,6 +191,16 @@ struct SoftmaxParams {
 };
 void launch_softmax(const SoftmaxParams& p, hipStream_t s);
 
+struct PreprocParams {
+    const unsigned char* in;   // [B][H][W][3] uint8
+    int B, H, W, crop_w;
+    const int* shift;          // [B] roll in pixels (out[x] = in[(x - shift) mod W]) or null
+    float mean[3], stdv[3];
+    float* out;                // [B][3][H][crop_w] fp32
+};
+void launch_preprocess(const PreprocParams& p, hipStream_t s);
+void launch_scatter_channels(const float* src, int C, long long P, Dst d0, Dst d1, int ndst, hipStream_t s);
+
 struct PoseOut { int32_t index; float prob, cos_v, sin_v, angle_deg; };
 void launch_postprocess(const float* heat, const float* ori, int B, int n, PoseOut* out, hipStream_t s);
 

@@ -181,6 +181,57 @@ void launch_postprocess(const float* heat, const float* ori, int B, int n, PoseO
     hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(1024), 0, s, heat, ori, n, out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Input pre-processing: uint8 HWC image (already decoded / resized on the host) ->
+// ToTensor (x/255) -> Normalize((x-mean)/std) (train_VIGOR.py:57-70) -> panorama roll
+// torch.roll(grd, shift, dims=2) (datasets.py:118) -> FoV width crop grd[..., :crop_w]
+// (train_VIGOR.py:272-273), written as the fp32 NCHW tensor forward() consumes.  Same fp32 operation
+// order as torchvision (divide, subtract, divide), so results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_kernel(const PreprocParams p) {
+    const long long total = (long long)p.B * 3 * p.H * p.crop_w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % p.crop_w);
+        long long t = i / p.crop_w;
+        const int y = (int)(t % p.H);
+        t /= p.H;
+        const int c = (int)(t % 3);
+        const int b = (int)(t / 3);
+        int sx = x - (p.shift ? p.shift[b] : 0);
+        sx %= p.W;
+        if (sx < 0) sx += p.W;
+        const float v = (float)p.in[(((size_t)b * p.H + y) * p.W + sx) * 3 + c];
+        p.out[i] = (v / 255.0f - p.mean[c]) / p.stdv[c];
+    }
+}
+
+void launch_preprocess(const PreprocParams& p, hipStream_t s) {
+    const long long total = (long long)p.B * 3 * p.H * p.crop_w;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, s, p);
+}
+
+// contiguous [P][C] -> channel window of an NHWC buffer (cached aerial taps -> decoder concat buffers)
+__global__ __launch_bounds__(256) void scatter_channels_kernel(const float* src, int C, long long P, Dst d0, Dst d1, int ndst) {
+    const int c4n = C >> 2;
+    const long long total = P * c4n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i / c4n;
+        const int c4 = (int)(i - pix * c4n);
+        const float4 v = *reinterpret_cast<const float4*>(src + pix * C + c4 * 4);
+        *reinterpret_cast<float4*>(d0.ptr + pix * d0.ld + d0.coff + c4 * 4) = v;
+        if (ndst > 1) *reinterpret_cast<float4*>(d1.ptr + pix * d1.ld + d1.coff + c4 * 4) = v;
+    }
+}
+
+void launch_scatter_channels(const float* src, int C, long long P, Dst d0, Dst d1, int ndst, hipStream_t s) {
+    const long long total = P * (C >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(scatter_channels_kernel, dim3(blocks), dim3(256), 0, s, src, C, P, d0, d1, ndst);
+}
+
 // NHWC view -> NCHW copy (debug taps only).
 __global__ void nhwc_to_nchw_kernel(const float* in, int in_ld, int coff, int C, int B, int HW, float* out) {
     const long long total = (long long)B * C * HW;

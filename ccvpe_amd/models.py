@@ -208,6 +208,44 @@ class _CVMBase(nn.Module):
         _lib.check(rc, "ccvpe_forward")
         return tensors
 
+    # ---- aerial-side caching for streaming -------------------------------
+    def encode_aerial(self, sat: torch.Tensor) -> torch.Tensor:
+        """Encode aerial images once; the returned device buffer feeds forward_cached() for any number of
+        ground frames that share the tile (Oxford RobotCar reuses tiles, datasets.py:306-317)."""
+        if self.training:
+            raise RuntimeError("ccvpe_amd runs the inference path only: call .eval() first")
+        if not sat.is_cuda or sat.dim() != 4 or tuple(sat.shape[1:]) != (3,) + spec.SAT_HW:
+            raise ValueError("sat must be a cuda tensor [B,3,512,512]")
+        sat = sat.detach().to(torch.float32).contiguous()
+        self._ensure_handle(sat.device)
+        lib = _lib.load()
+        B = sat.shape[0]
+        nbytes = lib.ccvpe_aerial_cache_bytes(self._handle, B)
+        cache = torch.empty(nbytes // 4, dtype=torch.float32, device=sat.device)
+        stream = torch.cuda.current_stream(sat.device).cuda_stream
+        _lib.check(lib.ccvpe_encode_aerial(self._handle, C.c_void_p(sat.data_ptr()), B, C.c_void_p(cache.data_ptr()),
+                                           C.c_void_p(stream)), "ccvpe_encode_aerial")
+        cache._ccvpe_batch = B
+        return cache
+
+    def forward_cached(self, grd: torch.Tensor, cache: torch.Tensor):
+        """forward(grd, sat) with the aerial side taken from encode_aerial(sat)."""
+        if self.training:
+            raise RuntimeError("ccvpe_amd runs the inference path only: call .eval() first")
+        if not grd.is_cuda or grd.dim() != 4 or grd.shape[1] != 3:
+            raise ValueError("grd must be a cuda tensor [B,3,H,W]")
+        grd = grd.detach().to(torch.float32).contiguous()
+        self._ensure_handle(grd.device)
+        B = grd.shape[0]
+        if getattr(cache, "_ccvpe_batch", B) != B:
+            raise ValueError("cache was encoded for a different batch size")
+        out, tensors = self._alloc_outputs(B, grd.device)
+        stream = torch.cuda.current_stream(grd.device).cuda_stream
+        rc = _lib.load().ccvpe_forward_cached(self._handle, C.c_void_p(grd.data_ptr()), grd.shape[2], grd.shape[3],
+                                              C.c_void_p(cache.data_ptr()), B, C.byref(out), C.c_void_p(stream))
+        _lib.check(rc, "ccvpe_forward_cached")
+        return tensors
+
     # ---- extras beyond the reference surface ------------------------------------------------
     def postprocess(self, heatmap: torch.Tensor, ori: torch.Tensor) -> Dict[str, torch.Tensor]:
         """Device-side version of the per-sample loop in train_VIGOR.py:297-316."""

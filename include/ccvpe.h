@@ -112,6 +112,24 @@ int ccvpe_forward(ccvpe_handle h, const float* grd, int32_t grd_h, int32_t grd_w
 int ccvpe_postprocess(ccvpe_handle h, const float* heatmap, const float* ori, int32_t batch,
                       ccvpe_pose* poses, void* stream);
 
+/* Aerial-side caching for streaming (reference datasets.py:306-317 reuses aerial tiles across frames, the
+ * reference model still re-encodes them every call): encode once, then run ground encoder + matching +
+ * decoders against the cached aerial encoding.  `cache` is caller-owned DEVICE memory of
+ * ccvpe_aerial_cache_bytes(h, batch) bytes; batch <= micro_batch.  forward_cached(grd, encode(sat)) ==
+ * forward(grd, sat). */
+size_t ccvpe_aerial_cache_bytes(ccvpe_handle h, int32_t batch);
+int ccvpe_encode_aerial(ccvpe_handle h, const float* sat, int32_t batch, void* cache, void* stream);
+int ccvpe_forward_cached(ccvpe_handle h, const float* grd, int32_t grd_h, int32_t grd_w, const void* cache,
+                         int32_t batch, const ccvpe_outputs* out, void* stream);
+
+/* Input pre-processing on device (reference train_VIGOR.py:57-70 ToTensor + Normalize, datasets.py:118
+ * torch.roll(grd, shift, dims=2), train_VIGOR.py:272-273 FoV crop): uint8 HWC images [B,H,W,3] (decoded and
+ * resized on the host) -> float32 NCHW [B,3,H,crop_w] with out[..., x] = norm(in[..., (x - shift[b]) mod W, :]).
+ * `shift` is DEVICE memory [B] or NULL; mean/std are host arrays of 3.  Bit-identical to torchvision's fp32
+ * (x/255 - mean)/std. */
+int ccvpe_preprocess(const uint8_t* hwc, int32_t batch, int32_t H, int32_t W, const int32_t* shift, int32_t crop_w,
+                     const float mean[3], const float stdv[3], float* out_nchw, void* stream);
+
 /* Debug taps: when enabled, intermediate tensors of the next forward call stay resident and can be
  * copied out by name as NCHW float32 into HOST memory (`capacity` in floats).  Returns the number
  * of floats written via *n_out.  Names: see DESIGN.md (e.g. "sat_block15", "loc_level6"). */

@@ -204,3 +204,18 @@ def postprocess(heatmap: torch.Tensor, ori: torch.Tensor):
     a = torch.rad2deg(torch.acos(cs.clamp(-1, 1)))
     deg = torch.where(sn < 0, (-a) % 360, a)
     return idx, prob, cs, sn, deg
+
+
+def preprocess(img_u8_hwc, shift=None, crop_w=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """CPU restatement of the input pipeline after decode/resize: ToTensor + Normalize
+    (train_VIGOR.py:57-70), panorama roll torch.roll(grd, shift, dims=2) (datasets.py:118), FoV width crop
+    grd[..., :crop_w] (train_VIGOR.py:272-273).  img_u8_hwc: uint8 tensor [B,H,W,3]."""
+    x = img_u8_hwc.permute(0, 3, 1, 2).to(torch.float32) / 255.0                 # ToTensor
+    m = torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(1, 3, 1, 1)
+    x = (x - m) / s                                                              # Normalize
+    if shift is not None:
+        x = torch.stack([torch.roll(x[b], int(shift[b]), dims=2) for b in range(x.shape[0])])
+    if crop_w is not None:
+        x = x[..., :crop_w]
+    return x.contiguous()
