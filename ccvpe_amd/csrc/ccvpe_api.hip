@@ -185,6 +185,7 @@ struct Plan {
     // arguments never change; the caller's buffers are reached by D2D copies outside the graph
     bool use_graph = false;
     Tensor io_grd, io_sat, io_logits, io_heat, io_ori, io_ms[6];
+    Tensor tune_cache;            // encode plans: stand-in for the caller's cache while the plan is being autotuned
     hipGraphExec_t exec = nullptr;
     int runs = 0;
     ~Plan() { if (exec) (void)hipGraphExecDestroy(exec); }
@@ -216,6 +217,7 @@ struct Plan {
             for (int id : ops[i].uses) { first[id] = std::min(first[id], i); last[id] = std::max(last[id], i); }
         if (debug) for (int i = 0; i < n; ++i) last[i] = 1 << 30;
         if (scratch.id >= 0) { first[scratch.id] = 0; last[scratch.id] = 1 << 30; }
+        if (tune_cache.id >= 0) { first[tune_cache.id] = 0; last[tune_cache.id] = 1 << 30; }
         if (use_graph)
             for (const Tensor* t : {&io_grd, &io_sat, &io_logits, &io_heat, &io_ori, &io_ms[0], &io_ms[1], &io_ms[2], &io_ms[3], &io_ms[4], &io_ms[5]}) {
                 first[t->id] = 0; last[t->id] = 1 << 30;
@@ -922,6 +924,7 @@ static int build_aerial_plan(ccvpe_handle_s* h, Plan& pl, int B) {
     size_t coff[6];
     cache_layout(vs, B, coff);
     const int D = vs.sat_desc;
+    pl.tune_cache = pl.alloc(B, 8, 8, D);
     {
         const PackedConv* pc = &h->sat_desc;
         Tensor x = senc.vol;
@@ -1081,6 +1084,7 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
     Ctx c;
     c.arena = h->arena; c.off = &pl.off; c.stream = nullptr;
     c.splitk_scratch = c.ptr(pl.scratch); c.splitk_floats = Plan::SPLITK_FLOATS;
+    if (pl.tune_cache.id >= 0) c.cache_out = c.ptr(pl.tune_cache);
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
