@@ -108,6 +108,8 @@ def main():
                     help="fp32 = exact fp32 MFMA (default, the headline); bf16x3 = 3-term bf16 split (opt-in, ~1e-5 rel.)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-precision", action="store_true")
+    ap.add_argument("--cached-aerial", action="store_true",
+                    help="streaming mode: the aerial tile is encoded once (outside the timed region) and every step runs forward_cached")
     ap.add_argument("--breakdown", action="store_true", help="print the per-launch profile table to stderr")
     args = ap.parse_args()
 
@@ -117,7 +119,9 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    # CCVPE_BENCH_SHARE_GPU=1 (test rigs only) lets several ranks share one GPU, with CCVPE_DIST_BACKEND=gloo
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % ndev if os.environ.get("CCVPE_BENCH_SHARE_GPU") else local_rank)
     torch.cuda.set_device(dev)
 
     variant, kw, fov = WORKLOADS[args.workload]
@@ -125,8 +129,10 @@ def main():
     g, s = weights.generate_inputs(variant, args.batch, rank, fov)
     grd, sat = torch.from_numpy(g).to(dev), torch.from_numpy(s).to(dev)
 
+    cache = model.encode_aerial(sat) if args.cached_aerial else None
+
     def step():
-        outs = model(grd, sat)
+        outs = model.forward_cached(grd, cache) if cache is not None else model(grd, sat)
         post = model.postprocess(outs[1], outs[2])
         rows = torch.stack([post["index"].to(torch.float32), post["prob"], post["cos"], post["sin"], post["angle_deg"]], dim=1)
         return D.gather_results(rows)
@@ -158,7 +164,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "f32 via bf16x3 split (3 bf16 MFMA per product, f32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": args.workload, "variant": variant, "batch_per_gpu": args.batch,
+        "config": {"workload": args.workload + ("+cached_aerial" if args.cached_aerial else ""), "variant": variant, "batch_per_gpu": args.batch,
                    "global_batch": world * args.batch, "grd": list(grd.shape[1:]), "sat": list(sat.shape[1:]),
                    "parallelism": f"image-parallel x{world}, all_gather of 20 B/query results"},
     }

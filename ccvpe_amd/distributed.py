@@ -27,7 +27,7 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("CCVPE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -58,8 +58,14 @@ def gather_results(local: torch.Tensor, n_items: int | None = None) -> torch.Ten
     pad = local
     if local.shape[0] < width:
         pad = torch.cat([local, local.new_zeros((width - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
-    out = local.new_empty((world * width,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, pad.contiguous())
+    if dist.get_backend() == "gloo" and pad.is_cuda:   # test rigs only: gloo gathers through host memory
+        host = pad.cpu().contiguous()
+        out_h = host.new_empty((world * width,) + tuple(host.shape[1:]))
+        dist.all_gather_into_tensor(out_h, host)
+        out = out_h.to(local.device)
+    else:
+        out = local.new_empty((world * width,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, pad.contiguous())
     if all(s == width for s in sizes):
         return out
     return torch.cat([out[r * width: r * width + sizes[r]] for r in range(world)], dim=0)
@@ -73,6 +79,8 @@ def barrier() -> None:
 def max_over_ranks(value: float, device: torch.device | str = "cpu") -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
