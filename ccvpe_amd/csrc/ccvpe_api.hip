@@ -347,7 +347,7 @@ static int pack_conv(ccvpe_handle_s* h, PackedConv& pc, int N, int taps, int cin
     std::vector<float> w((size_t)npad * kpad, 0.f);
     for (int n = 0; n < N; ++n)
         for (int t = 0; t < taps; ++t)
-            for (int c = 0; c < cin; ++c) w[(size_t)n * kpad + t * cinp + cmap[c]] = get(n, t, c);
+            for (int c = 0; c < cin; ++c) w[(size_t)n * kpad + conv_igemm_k_index(cinp, taps, t, cmap[c])] = get(n, t, c);
     pc.N = N; pc.Kpad = kpad; pc.nchunks = K / 8; pc.cinp = cinp; pc.KH = KH; pc.KW = KW;
     int rc = upload(h, w, &pc.w);
     if (rc) return rc;

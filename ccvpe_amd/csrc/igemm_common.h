@@ -20,6 +20,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// K order of the implicit GEMM (matches pack_conv on the host): channel-group major, tap minor -
+//   for each group of 32 input channels: for each filter tap: the group's (up to 4) 8-channel chunks.
+// Consecutive K tiles therefore re-read the SAME 128-byte lines of the activation at neighbouring pixels (the
+// 3x3 halo), which keeps the 9x tap reuse in L1/L2 instead of the Infinity Cache; with tap-major order a
+// workgroup only returned to a line after walking all channels of the tap (FETCH_SIZE 8-9x the input bytes).
+// chunk g -> (tap, first channel c0); exact multiply-shift divisions (verified on the host per layer).
+__device__ __forceinline__ void chunk_to_tap(const ConvParams& p, int g, int& tap, int& c0) {
+    if (g < p.kfull_chunks) {
+        const int cg = (int)(((unsigned)g * (unsigned)p.div_4t_mul) >> 20);   // g / (4*T)
+        const int idx = g - cg * p.taps4;
+        tap = idx >> 2;
+        c0 = cg * 32 + (idx & 3) * 8;
+    } else {
+        const int idx = g - p.kfull_chunks;
+        tap = (idx * p.div_nc_mul) >> 8;                                        // idx / nc, nc in {1,2,3}
+        c0 = p.kfull_c0 + (idx - tap * p.knc) * 8;
+    }
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACT_SWISH) return v / (1.f + __expf(-v));

@@ -47,8 +47,14 @@ struct ConvParams {
     int M;                     // B*OH*OW
     unsigned in_bytes;         // extent of `in` for the bounds-checked buffer loads (< 2 GiB)
     unsigned gate_bytes;
-    int div_cin8_mul;          // filled by launch_conv_igemm: chunk / (Cin/8) == (chunk * mul) >> 20
-    int div_kw_mul;            //                              tap / KW       == (tap * mul) >> 5
+    // filled by launch_conv_igemm (conv_igemm_prepare): K-order arithmetic, see chunk_to_tap()
+    int taps4;                 // 4 * KH*KW
+    int kfull_chunks;          // chunks covered by whole 32-channel groups = (Cin/32) * 4 * taps
+    int kfull_c0;              // (Cin/32)*32: first channel of the partial group
+    int knc;                   // chunks per tap in the partial group (Cin%32)/8
+    int div_4t_mul;            // g / taps4      == (g * mul) >> 20
+    int div_nc_mul;            // idx / knc      == (idx * mul) >> 8
+    int div_kw_mul;            // tap / KW       == (tap * mul) >> 5
     int vec_epi;               // filled by launch_conv_igemm: 16-byte epilogue stores are legal
     int splitk;                // filled by launch_conv_igemm from the cfg word: K split over gridDim.z
     float* partial;            // split-K slab scratch [splitk][M][N] (null = split-K unavailable)
@@ -61,6 +67,7 @@ int conv_igemm_num_tiles();
 double conv_igemm_tile_util(const ConvParams& p, int tile);
 long long conv_igemm_tile_blocks(const ConvParams& p, int tile);
 int conv_igemm_prepare(ConvParams& p);
+int conv_igemm_k_index(int cin, int taps, int tap, int c);   // packed-weight column of (tap, channel)
 int launch_conv_igemm(const ConvParams& p, int tile, hipStream_t s);   // 0, or -1 for unsupported geometry
 int conv_igemm_npad();       // row padding of packed weights (multiple every tile divides)
 bool conv_igemm_tile_is_bf16x3(int tile);

@@ -86,7 +86,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         a_ix[j] = ix0;
         a_gb[j] = (b * p.Cin + (kq & 1) * 4) * 4;
     }
-    const int cin8 = p.Cin >> 3;
     const float* wrow[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j) wrow[j] = p.wpk + (size_t)min(n0 + r0 + 32 * j, p.Npad - 1) * p.Kpad + kq * 4;
@@ -97,19 +96,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #define CCVPE_LOAD_TILE(kt)                                                                              \
     {                                                                                                    \
         const int g = (kt) * 4 + (kq >> 1);                                                              \
-        const int tap = (int)(((unsigned)g * (unsigned)p.div_cin8_mul) >> 20);                           \
-        const int cc = g - tap * cin8;                                                                   \
+        int tap, c0;                                                                                     \
+        chunk_to_tap(p, g, tap, c0);                                                                     \
         const int ky = (tap * p.div_kw_mul) >> 5;                                                        \
         const int kx = tap - ky * p.KW;                                                                  \
         const bool gok = g < p.nchunks;                                                                  \
-        const int koff = ((ky * p.W + kx) * p.in_ld + cc * 8) * 4;                                       \
+        const int koff = ((ky * p.W + kx) * p.in_ld + c0) * 4;                                           \
         _Pragma("unroll") for (int j = 0; j < AR; ++j) {                                                 \
             const int iy = a_iy[j] + ky, ix = a_ix[j] + kx;                                              \
             const bool ok = gok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);       \
             const unsigned off = ok ? (unsigned)(a_base[j] + koff) : OOB;                                \
             ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0)); \
             if (GATE) {                                                                                  \
-                rg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gate_rsrc, ok ? (unsigned)(a_gb[j] + cc * 32) : OOB, 0, 0)); \
+                rg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gate_rsrc, ok ? (unsigned)(a_gb[j] + c0 * 4) : OOB, 0, 0)); \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int j = 0; j < BR; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (kt) * BK); \
@@ -368,11 +367,26 @@ static int find_div_mul(int d, int limit) {
 }
 
 int conv_igemm_prepare(ConvParams& p) {
-    const int cin8 = p.Cin / 8;
+    const int taps = p.KH * p.KW;
     const int limit = p.Kpad / 8 + 8;
-    const int mul = find_div_mul(cin8, limit);
+    p.taps4 = 4 * taps;
+    p.kfull_chunks = (p.Cin / 32) * 4 * taps;
+    p.kfull_c0 = (p.Cin / 32) * 32;
+    p.knc = (p.Cin % 32) / 8;
+    const int mul = find_div_mul(p.taps4, limit);
     if (mul < 0 || (long long)limit * mul >= (1LL << 32)) return -1;
-    p.div_cin8_mul = mul;
+    p.div_4t_mul = mul;
+    p.div_nc_mul = 256;   // knc == 0 or 1: idx / 1
+    if (p.knc > 1) {
+        int m = -1;
+        for (int c = 1; c < 512 && m < 0; ++c) {
+            bool ok = true;
+            for (int i = 0; i < 4 * 16 && ok; ++i) ok = ((i * c) >> 8) == i / p.knc;
+            if (ok) m = c;
+        }
+        if (m < 0) return -1;
+        p.div_nc_mul = m;
+    }
     // tap / KW for tap < 16: (tap * m) >> 5
     int kwm = -1;
     for (int m = 1; m < 64 && kwm < 0; ++m) {
@@ -383,6 +397,17 @@ int conv_igemm_prepare(ConvParams& p) {
     if (kwm < 0) return -1;
     p.div_kw_mul = kwm;
     return 0;
+}
+
+// host-side inverse of chunk_to_tap(): GEMM k index of (tap, channel c) for a layer with `cin` (padded)
+// input channels and `taps` filter taps
+int conv_igemm_k_index(int cin, int taps, int tap, int c) {
+    const int full = cin / 32;
+    const int cg = c / 32;
+    int g;
+    if (cg < full) g = cg * 4 * taps + tap * 4 + (c % 32) / 8;
+    else g = full * 4 * taps + tap * ((cin % 32) / 8) + (c - full * 32) / 8;
+    return g * 8 + (c % 8);
 }
 
 int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {

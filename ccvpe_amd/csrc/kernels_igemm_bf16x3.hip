@@ -88,7 +88,6 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
         a_ix[j] = ix0;
         a_gb[j] = (b * p.Cin + (kq & 1) * 4) * 4;
     }
-    const int cin8 = p.Cin >> 3;
     // weight planes: thread -> (row = tid>>2 (+64j), 16-byte chunk = tid&3)
     const int wch = tid & 3, wr0 = tid >> 2;
     const unsigned short* wrow_h[BRH];
@@ -107,19 +106,19 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
 #define CCVPE_LOAD_TILE(kt)                                                                              \
     {                                                                                                    \
         const int g = (kt) * 4 + (kq >> 1);                                                              \
-        const int tap = (int)(((unsigned)g * (unsigned)p.div_cin8_mul) >> 20);                           \
-        const int cc = g - tap * cin8;                                                                   \
+        int tap, c0;                                                                                     \
+        chunk_to_tap(p, g, tap, c0);                                                                     \
         const int ky = (tap * p.div_kw_mul) >> 5;                                                        \
         const int kx = tap - ky * p.KW;                                                                  \
         const bool gok = g < p.nchunks;                                                                  \
-        const int koff = ((ky * p.W + kx) * p.in_ld + cc * 8) * 4;                                       \
+        const int koff = ((ky * p.W + kx) * p.in_ld + c0) * 4;                                           \
         _Pragma("unroll") for (int j = 0; j < AR; ++j) {                                                 \
             const int iy = a_iy[j] + ky, ix = a_ix[j] + kx;                                              \
             const bool ok = gok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);       \
             const unsigned off = ok ? (unsigned)(a_base[j] + koff) : OOB;                                \
             ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0)); \
             if (GATE) {                                                                                  \
-                rg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gate_rsrc, ok ? (unsigned)(a_gb[j] + cc * 32) : OOB, 0, 0)); \
+                rg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gate_rsrc, ok ? (unsigned)(a_gb[j] + c0 * 4) : OOB, 0, 0)); \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int j = 0; j < BRH; ++j) {                                                \
