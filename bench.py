@@ -59,6 +59,19 @@ def build_model(variant, kw, dev, micro_batch, precision="fp32"):
     return m.to(dev).eval()
 
 
+def traffic_from_profiles(kernel: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (bench.py cannot run
+    the profiler on itself): profiles/r01_traffic.json = 2*FETCH_SIZE + WRITE_SIZE for one representative launch
+    (decoder conv4.0 at batch 32; its algorithmic bytes are in the same file).  None if the dominant kernel of this
+    run is a different instantiation."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            t = json.load(fh)
+        return t["hbm_bytes_per_launch"] if t.get("kernel") == kernel else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def usable_cores() -> int:
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (os.cpu_count()
     reports the host's cores on a shared box and oversubscribes the intra-op pool badly)."""
@@ -188,7 +201,7 @@ def main():
             "achieved": fl / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "avg_launch_ms": ms / cnt, "flops_per_launch": fl / cnt,
-            "traffic": None,
+            "traffic": traffic_from_profiles(dom),
             "all_mfma_kernels": {"achieved": all_fl / (all_ms * 1e-3) / 1e12, "frac": all_fl / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                  "share_of_step": all_ms / total_ms},
             "hbm_kernels_share_of_step": 1.0 - all_ms / total_ms,
