@@ -120,6 +120,8 @@ struct PackedConv {
 };
 struct BlockW {
     PackedConv expand, project;
+    float* exp_lin = nullptr;     // [mid][cinp16] expand weights for the fused expand+depthwise kernel
+    int exp_cinp = 0;
     float *dw_w = nullptr, *dw_b = nullptr, *se_w1 = nullptr, *se_b1 = nullptr, *se_w2 = nullptr, *se_b2 = nullptr;
     int sq = 0;
 };
@@ -258,6 +260,7 @@ struct ccvpe_handle_s {
     bool finalized = false;
     bool debug = false;
     bool autotune = true;
+    bool fuse_mbconv = true;      // CCVPE_FUSE_MBCONV=0 falls back to expand GEMM + depthwise launches
     bool fuse_level1 = true;      // CCVPE_FUSE_L1=0 falls back to deconv / conv / tail launches
     int graph_mode = -1;          // -1 auto (plans of <= 4 samples replay a hipGraph), 0 never, 1 always
     hipStream_t capture_stream = nullptr;
@@ -411,6 +414,15 @@ static int build_encoder(ccvpe_handle_s* h, EncoderW& e, const std::string& p) {
         std::string q = p + "._blocks." + std::to_string(i);
         const int mid = b.cin * b.e;
         if (b.e != 1 && (rc = pack_pointwise_bn(h, bw.expand, q + "._expand_conv.weight", q + "._bn0", mid, b.cin))) return rc;
+        if (b.e != 1 && mbconv_front_supported(b.k, b.s, b.cin, mid)) {
+            const auto& w = h->host[q + "._expand_conv.weight"];
+            BnFold f = fold_bn(h, q + "._bn0");
+            bw.exp_cinp = round_up(b.cin, 16);
+            std::vector<float> lin((size_t)mid * bw.exp_cinp, 0.f);
+            for (int n = 0; n < mid; ++n)
+                for (int c = 0; c < b.cin; ++c) lin[(size_t)n * bw.exp_cinp + c] = w[(size_t)n * b.cin + c] * f.scale[n];
+            if ((rc = upload(h, lin, &bw.exp_lin))) return rc;
+        }
         {
             const auto& w = h->host[q + "._depthwise_conv.weight"];
             BnFold f = fold_bn(h, q + "._bn1");
@@ -563,6 +575,22 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         const std::string bn = tag + ".b" + std::to_string(i);
         Tensor xin = cur;
         Tensor e = xin;
+        static_pad(b.k, b.s, lo, hi);
+        const int oh = conv_out(ch, b.k, b.s), ow = conv_out(cw, b.k, b.s);
+        const bool fused = h->fuse_mbconv && b.e != 1 && bw.exp_lin != nullptr;
+        Tensor d = pl.alloc(B, oh, ow, mid);
+        const int S = fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid);
+        Tensor pool = pl.alloc(B, 1, S, mid);
+        if (fused) {
+            MbFrontParams mp{};
+            mp.B = B; mp.H = ch; mp.W = cw; mp.Cin = b.cin; mp.cinp = bw.exp_cinp; mp.mid = mid;
+            mp.we = bw.exp_lin; mp.be = bw.expand.bias; mp.wd = bw.dw_w; mp.bd = bw.dw_b;
+            mp.k = b.k; mp.s = b.s; mp.pad_t = lo; mp.pad_l = lo; mp.circular = circular; mp.OH = oh; mp.OW = ow;
+            pl.add(bn + ".expand_dw", {xin, d, pool}, [=](const Ctx& c) {
+                MbFrontParams q = mp; q.x = c.ptr(xin); q.out = c.ptr(d); q.pool = c.ptr(pool);
+                launch_mbconv_front(q, c.stream);
+            }, 2.0 * B * ch * cw * b.cin * mid + 2.0 * B * oh * ow * mid * b.k * b.k, 4.0 * B * ((double)ch * cw * b.cin + (double)oh * ow * mid));
+        } else {
         if (b.e != 1) {
             e = pl.alloc(B, ch, cw, mid);
             const PackedConv* pc = &bw.expand;
@@ -573,11 +601,6 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
                 c.launch_conv(p, tile);
             }, 2.0 * B * ch * cw * b.cin * mid, 4.0 * B * ch * cw * (b.cin + mid));
         }
-        static_pad(b.k, b.s, lo, hi);
-        const int oh = conv_out(ch, b.k, b.s), ow = conv_out(cw, b.k, b.s);
-        Tensor d = pl.alloc(B, oh, ow, mid);
-        const int S = depthwise_strip_lanes(B, oh, ow, mid);
-        Tensor pool = pl.alloc(B, 1, S, mid);
         {
             DwParams dp{};
             dp.B = B; dp.H = ch; dp.W = cw; dp.C = mid; dp.OH = oh; dp.OW = ow; dp.k = b.k; dp.stride = b.s;
@@ -586,6 +609,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
                 DwParams q = dp; q.in = c.ptr(e); q.out = c.ptr(d); q.pool_partial = c.ptr(pool);
                 launch_depthwise(q, c.stream);
             }, 2.0 * B * oh * ow * mid * b.k * b.k, 4.0 * B * mid * ((double)ch * cw + (double)oh * ow));
+        }
         }
         Tensor gate = pl.alloc(B, 1, 1, mid);
         const int SC = std::max(1, std::min(16, S / 32));
@@ -974,6 +998,7 @@ int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
     if (const char* e = getenv("CCVPE_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_GRAPH")) h->graph_mode = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_FUSE_L1")) h->fuse_level1 = std::atoi(e) != 0;
+    if (const char* e = getenv("CCVPE_FUSE_MBCONV")) h->fuse_mbconv = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_PRECISION")) h->cfg.reserved[0] = (std::string(e) == "bf16x3") ? 1 : 0;
     if (h->cfg.reserved[0] != 0 && h->cfg.reserved[0] != 1) { delete h; return fail(CCVPE_EINVAL, "unknown precision mode %d", cfg->reserved[0]); }
     const int n = (int)(cfg->ori_noise / 18.f);

@@ -105,6 +105,23 @@ struct DwParams {
 void launch_depthwise(const DwParams& p, hipStream_t s);
 int depthwise_strip_lanes(int B, int OH, int OW, int C);
 
+// Fused expand (1x1 + BN + swish) + depthwise (k x k + BN + swish) + SE pooling partials (kernels_mbconv.hip)
+struct MbFrontParams {
+    const float* x;            // NHWC [B,H,W,Cin]
+    int B, H, W, Cin, cinp;    // cinp = Cin rounded up to 16 (weights zero padded)
+    int mid;                   // expanded channels, multiple of 48
+    const float* we;           // [mid][cinp], BN folded
+    const float* be;           // [mid]
+    const float* wd;           // [k*k][mid], BN folded
+    const float* bd;           // [mid]
+    int k, s, pad_t, pad_l, circular, OH, OW;
+    float* out;                // NHWC [B,OH,OW,mid]
+    float* pool;               // [B][tiles][mid]
+};
+void launch_mbconv_front(const MbFrontParams& p, hipStream_t s);
+int mbconv_front_tiles(int k, int s, int OH, int OW);
+bool mbconv_front_supported(int k, int s, int cin, int mid);
+
 struct SeParams {
     const float* pool_partial; // [B][S][C]
     int B, S, C, SQ;

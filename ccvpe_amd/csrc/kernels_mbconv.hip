@@ -1,0 +1,189 @@
+// Fused MBConv front half: 1x1 expand (+BN+swish) -> depthwise k x k (+BN+swish) -> SE pooling partials,
+// for the large-spatial blocks (1..4) of EfficientNet-B0 where the 6x-expanded tensor dominates HBM traffic.
+//
+// Reference: MBConvBlock.forward, efficientnet_pytorch/model.py:103-110 (expand conv + bn0 + swish, static
+// same/circular padding utils.py:254-358, depthwise conv + bn1 + swish) and :114 (global average pool).
+//
+// Unfused, block 1 writes a 96 x 256 x 256 fp32 tensor per aerial image (25 MB) only to read it back once.
+// Here a workgroup owns an output tile of the depthwise conv: the input pixels it depends on (tile + halo,
+// Cin <= 48 channels) are staged in LDS once; for each chunk of 48 expanded channels the expand GEMM
+// [pixels x Cin] x [Cin x 48] runs on v_mfma_f32_16x16x4_f32 into an LDS tile (positions outside the image are
+// forced to 0: the reference zero-pads the EXPANDED activation; horizontally-circular layers wrap instead),
+// the depthwise conv reads that tile on the VALU, and only the depthwise output leaves the chip together with
+// deterministic per-tile channel sums for the squeeze-excite pool.  The halo is recomputed (1.2-2.3x expand
+// FLOPs, which are negligible next to the saved traffic).
+#include "kernels.h"
+
+#include <algorithm>
+
+namespace ccvpe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int MC = 48;          // expanded channels per chunk (96, 144, 240 are multiples of 48)
+static constexpr int ES = MC + 4;      // floats per pixel in the E tile (208 B: conflict-free b128)
+
+__device__ __forceinline__ float swish_f(float v) { return v / (1.f + __expf(-v)); }
+
+// TW x TH output tile; input tile IW x IH = ((TW-1)*S + K) x ((TH-1)*S + K)
+template <int K, int S, int TW, int TH>
+__global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p) {
+    constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K;
+    constexpr int NIP = IW * IH;                 // input pixels in the tile
+    constexpr int NMT = (NIP + 15) / 16;         // m-tiles of the expand GEMM
+    constexpr int NOP = TW * TH;                 // output pixels
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int CP = p.cinp;                       // Cin padded to 16
+    const int XS = CP + 4;
+    float* Xs = smem;                            // [NIP][XS]
+    float* Ws = Xs + NIP * XS;                   // [MC][XS]   expand weights of the current chunk
+    float* Es = Ws + MC * XS;                    // [NIP][ES]
+    float* Rs = Es + NIP * ES;                   // [16][MC]   pooling reduction
+    unsigned char* Vs = reinterpret_cast<unsigned char*>(Rs + 16 * MC);   // [NIP] 1 = inside the image
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (p.OW + TW - 1) / TW;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
+
+    // ---- stage the input tile (zero outside; horizontal wrap for circular layers) ----
+    const int c4n = CP >> 2;
+    for (int i = tid; i < NIP * c4n; i += 256) {
+        const int px = i / c4n, c4 = i - px * c4n;
+        const int iy = iy0 + px / IW;
+        int ix = ix0 + px % IW;
+        bool ok = (unsigned)iy < (unsigned)p.H;
+        if (p.circular) { if (ix < 0) ix += p.W; else if (ix >= p.W) ix -= p.W; }
+        ok = ok && (unsigned)ix < (unsigned)p.W;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok && c4 * 4 < p.Cin) v = *reinterpret_cast<const f32x4*>(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.Cin + c4 * 4);
+        *reinterpret_cast<f32x4*>(Xs + px * XS + c4 * 4) = v;
+        if (c4 == 0) Vs[px] = ok ? 1 : 0;
+    }
+
+    const int kch = CP >> 4;
+    // depthwise thread mapping: 192 threads = 12 channel groups x 16 pixel slots (fixed group per thread so the
+    // pooling sums stay private and deterministic)
+    const int dg = tid % 12, dslot = tid / 12;
+    const bool dw_active = tid < 192;
+
+    for (int ch0 = 0; ch0 < p.mid; ch0 += MC) {
+        // expand weights of this chunk -> LDS
+        for (int i = tid; i < MC * c4n; i += 256) {
+            const int n = i / c4n, c4 = i - n * c4n;
+            *reinterpret_cast<f32x4*>(Ws + n * XS + c4 * 4) = *reinterpret_cast<const f32x4*>(p.we + (size_t)(ch0 + n) * CP + c4 * 4);
+        }
+        __syncthreads();
+        // ---- expand GEMM: units = (m-tile, n-tile of 16 channels), two chains per wave ----
+        for (int u0 = wave; u0 < NMT * 3; u0 += 8) {
+            const int u1 = u0 + 4;
+            const int mt0 = u0 / 3, nt0 = u0 - mt0 * 3;
+            const int mt1 = u1 / 3, nt1 = u1 - mt1 * 3;
+            const float* a0p = Xs + min(mt0 * 16 + (lane & 15), NIP - 1) * XS + 4 * (lane >> 4);
+            const float* a1p = Xs + min(mt1 * 16 + (lane & 15), NIP - 1) * XS + 4 * (lane >> 4);
+            const float* b0p = Ws + (nt0 * 16 + (lane & 15)) * XS + 4 * (lane >> 4);
+            const float* b1p = Ws + (min(nt1, 2) * 16 + (lane & 15)) * XS + 4 * (lane >> 4);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            for (int kc = 0; kc < kch; ++kc) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(a0p + kc * 16);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(a1p + kc * 16);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(b0p + kc * 16);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(b1p + kc * 16);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w1.w, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int u = h2 ? u1 : u0;
+                if (u >= NMT * 3) continue;
+                const int mt = h2 ? mt1 : mt0, nt = h2 ? nt1 : nt0;
+                const f32x4 acc = h2 ? acc1 : acc0;
+                const float be = p.be[ch0 + nt * 16 + (lane & 15)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int px = mt * 16 + (lane >> 4) * 4 + r;
+                    if (px < NIP) Es[px * ES + nt * 16 + (lane & 15)] = Vs[px] ? swish_f(acc[r] + be) : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- depthwise k x k from the E tile, BN + swish, store, pooling partial ----
+        if (dw_active) {
+            const int c = ch0 + dg * 4;
+            const f32x4 bd = *reinterpret_cast<const f32x4*>(p.bd + c);
+            f32x4 pool = {0.f, 0.f, 0.f, 0.f};
+            for (int op = dslot; op < NOP; op += 16) {
+                const int oyl = op / TW, oxl = op - oyl * TW;
+                const int oy = oy0 + oyl, ox = ox0 + oxl;
+                if (oy >= p.OH || ox >= p.OW) continue;
+                f32x4 acc = bd;
+                const float* ep = Es + ((oyl * S) * IW + oxl * S) * ES + dg * 4;
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(ep + (ky * IW + kx) * ES);
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(p.wd + (size_t)(ky * K + kx) * p.mid + c);
+                        acc += v * w;
+                    }
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = swish_f(acc[e]);
+                pool += o;
+                *reinterpret_cast<f32x4*>(p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.mid + c) = o;
+            }
+            *reinterpret_cast<f32x4*>(Rs + dslot * MC + dg * 4) = pool;
+        }
+        __syncthreads();
+        if (tid < MC) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += Rs[i * MC + tid];
+            p.pool[((size_t)b * gridDim.x + tile) * p.mid + ch0 + tid] = s;
+        }
+        // the next chunk's first barrier (after the weight load) orders these reads before Rs/Es/Ws are rewritten
+    }
+}
+
+template <int K, int S, int TW, int TH>
+static void launch_mb(const MbFrontParams& p, hipStream_t s) {
+    constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K, NIP = IW * IH;
+    const int XS = p.cinp + 4;
+    const size_t lds = ((size_t)NIP * XS + (size_t)MC * XS + (size_t)NIP * ES + 16 * MC) * sizeof(float) + ((NIP + 15) & ~15);
+    static size_t set = 0;
+    auto kern = mbconv_front_kernel<K, S, TW, TH>;
+    if (lds > set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = lds; }
+    const int tiles = ((p.OW + TW - 1) / TW) * ((p.OH + TH - 1) / TH);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.B), dim3(256), lds, s, p);
+}
+
+// output tile per (k, stride): stride-1 blocks 8x8, stride-2 blocks 8x4 (k3) / 8x2 (k5) - their input tiles are
+// (2T+k-2)^2-ish and must leave room for two workgroups per CU
+static void tile_of(int k, int s, int& tw, int& th) { tw = 8; th = s == 1 ? 8 : (k == 3 ? 4 : 2); }
+
+int mbconv_front_tiles(int k, int s, int OH, int OW) {
+    int tw, th;
+    tile_of(k, s, tw, th);
+    return ((OW + tw - 1) / tw) * ((OH + th - 1) / th);
+}
+
+bool mbconv_front_supported(int k, int s, int cin, int mid) {
+    return (k == 3 || k == 5) && (s == 1 || s == 2) && cin % 8 == 0 && cin <= 48 && mid % MC == 0;
+}
+
+void launch_mbconv_front(const MbFrontParams& p, hipStream_t s) {
+    if (p.k == 3 && p.s == 1) launch_mb<3, 1, 8, 8>(p, s);
+    else if (p.k == 3 && p.s == 2) launch_mb<3, 2, 8, 4>(p, s);
+    else if (p.k == 5 && p.s == 1) launch_mb<5, 1, 8, 8>(p, s);
+    else launch_mb<5, 2, 8, 2>(p, s);
+}
+
+}  // namespace ccvpe
