@@ -23,7 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int MC = 48;          // expanded channels per chunk (96, 144, 240 are multiples of 48)
 static constexpr int ES = MC + 4;      // floats per pixel in the E tile (208 B: conflict-free b128)
 
-__device__ __forceinline__ float swish_f(float v) { return v / (1.f + __expf(-v)); }
+__device__ __forceinline__ float swish_f(float v) { return __fdividef(v, 1.f + __expf(-v)); }
 
 // TW x TH output tile; input tile IW x IH = ((TW-1)*S + K) x ((TH-1)*S + K)
 template <int K, int S, int TW, int TH>
@@ -117,28 +117,41 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
         __syncthreads();
         // ---- depthwise k x k from the E tile, BN + swish, store, pooling partial ----
         if (dw_active) {
+            // thread = (channel group dg, strip of PPT adjacent output pixels of one row): every filter tap's weight
+            // is loaded once per chunk and the strip's input columns are read from LDS once per filter row
+            constexpr int PPT = NOP / 16;                 // 4 (8x8), 2 (8x4) or 1 (8x2)
+            constexpr int SPR = TW / PPT;                 // strips per row
+            constexpr int NCOL = (PPT - 1) * S + K;
             const int c = ch0 + dg * 4;
             const f32x4 bd = *reinterpret_cast<const f32x4*>(p.bd + c);
+            const int oyl = dslot / SPR, oxl = (dslot % SPR) * PPT;
+            f32x4 acc[PPT];
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) acc[i] = bd;
+            const float* ep = Es + ((oyl * S) * IW + oxl * S) * ES + dg * 4;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                f32x4 col[NCOL];
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j) col[j] = *reinterpret_cast<const f32x4*>(ep + (ky * IW + j) * ES);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(p.wd + (size_t)(ky * K + kx) * p.mid + c);
+#pragma unroll
+                    for (int i = 0; i < PPT; ++i) acc[i] += col[i * S + kx] * w;
+                }
+            }
             f32x4 pool = {0.f, 0.f, 0.f, 0.f};
-            for (int op = dslot; op < NOP; op += 16) {
-                const int oyl = op / TW, oxl = op - oyl * TW;
-                const int oy = oy0 + oyl, ox = ox0 + oxl;
-                if (oy >= p.OH || ox >= p.OW) continue;
-                f32x4 acc = bd;
-                const float* ep = Es + ((oyl * S) * IW + oxl * S) * ES + dg * 4;
 #pragma unroll
-                for (int ky = 0; ky < K; ++ky)
+            for (int i = 0; i < PPT; ++i) {
+                const int oy = oy0 + oyl, ox = ox0 + oxl + i;
+                if (oy < p.OH && ox < p.OW) {
+                    f32x4 o;
 #pragma unroll
-                    for (int kx = 0; kx < K; ++kx) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(ep + (ky * IW + kx) * ES);
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(p.wd + (size_t)(ky * K + kx) * p.mid + c);
-                        acc += v * w;
-                    }
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = swish_f(acc[e]);
-                pool += o;
-                *reinterpret_cast<f32x4*>(p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.mid + c) = o;
+                    for (int e = 0; e < 4; ++e) o[e] = swish_f(acc[i][e]);
+                    pool += o;
+                    *reinterpret_cast<f32x4*>(p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.mid + c) = o;
+                }
             }
             *reinterpret_cast<f32x4*>(Rs + dslot * MC + dg * 4) = pool;
         }
