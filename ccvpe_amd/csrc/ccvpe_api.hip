@@ -260,7 +260,7 @@ struct ccvpe_handle_s {
     bool finalized = false;
     bool debug = false;
     bool autotune = true;
-    bool fuse_mbconv = true;      // CCVPE_FUSE_MBCONV=0 falls back to expand GEMM + depthwise launches
+    int fuse_mbconv = 1;          // CCVPE_FUSE_MBCONV: 0 never, 1 where measured profitable (3x3 blocks), 2 every supported block
     bool fuse_level1 = true;      // CCVPE_FUSE_L1=0 falls back to deconv / conv / tail launches
     int graph_mode = -1;          // -1 auto (plans of <= 4 samples replay a hipGraph), 0 never, 1 always
     hipStream_t capture_stream = nullptr;
@@ -577,7 +577,8 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         Tensor e = xin;
         static_pad(b.k, b.s, lo, hi);
         const int oh = conv_out(ch, b.k, b.s), ow = conv_out(cw, b.k, b.s);
-        const bool fused = h->fuse_mbconv && b.e != 1 && bw.exp_lin != nullptr;
+        const bool fused = b.e != 1 && bw.exp_lin != nullptr &&
+                           (h->fuse_mbconv == 2 || (h->fuse_mbconv == 1 && mbconv_front_profitable(b.k)));
         Tensor d = pl.alloc(B, oh, ow, mid);
         const int S = fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid);
         Tensor pool = pl.alloc(B, 1, S, mid);
@@ -998,7 +999,7 @@ int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
     if (const char* e = getenv("CCVPE_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_GRAPH")) h->graph_mode = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_FUSE_L1")) h->fuse_level1 = std::atoi(e) != 0;
-    if (const char* e = getenv("CCVPE_FUSE_MBCONV")) h->fuse_mbconv = std::atoi(e) != 0;
+    if (const char* e = getenv("CCVPE_FUSE_MBCONV")) h->fuse_mbconv = std::atoi(e);
     if (const char* e = getenv("CCVPE_PRECISION")) h->cfg.reserved[0] = (std::string(e) == "bf16x3") ? 1 : 0;
     if (h->cfg.reserved[0] != 0 && h->cfg.reserved[0] != 1) { delete h; return fail(CCVPE_EINVAL, "unknown precision mode %d", cfg->reserved[0]); }
     const int n = (int)(cfg->ori_noise / 18.f);

@@ -121,6 +121,7 @@ struct MbFrontParams {
 void launch_mbconv_front(const MbFrontParams& p, hipStream_t s);
 int mbconv_front_tiles(int k, int s, int OH, int OW);
 bool mbconv_front_supported(int k, int s, int cin, int mid);
+bool mbconv_front_profitable(int k);
 
 struct SeParams {
     const float* pool_partial; // [B][S][C]

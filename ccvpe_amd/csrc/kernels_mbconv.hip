@@ -192,6 +192,12 @@ bool mbconv_front_supported(int k, int s, int cin, int mid) {
     return (k == 3 || k == 5) && (s == 1 || s == 2) && cin % 8 == 0 && cin <= 48 && mid % MC == 0;
 }
 
+// Measured on MI355X at batch 32 (round 1): the fused kernel wins for the 3x3 blocks (block 1: 0.41 vs 0.65 ms,
+// block 2: 0.33 vs 0.35, block 5: 0.11 vs 0.13) and loses for the 5x5 blocks (block 3: 0.44 vs 0.30, block 4:
+// 0.37 vs 0.19 - 25-tap depthwise from LDS plus 2.3x halo recompute make it latency-bound), so only k = 3 fuses
+// by default.
+bool mbconv_front_profitable(int k) { return k == 3; }
+
 void launch_mbconv_front(const MbFrontParams& p, hipStream_t s) {
     if (p.k == 3 && p.s == 1) launch_mb<3, 1, 8, 8>(p, s);
     else if (p.k == 3 && p.s == 2) launch_mb<3, 2, 8, 4>(p, s);
