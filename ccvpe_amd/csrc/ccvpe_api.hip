@@ -153,10 +153,11 @@ struct Ctx {
     const float* cache_in = nullptr;   // aerial cache consumed by a "cached" plan
     float* cache_out = nullptr;        // aerial cache produced by an "encode" plan
     float* ptr(const Tensor& t) const { return arena + (*off)[t.id]; }
+    mutable int conv_errors = 0;   // launches refused by launch_conv_igemm (unsupported geometry)
     void launch_conv(ConvParams& p, int cfg) const {
         p.partial = splitk_scratch;
         p.partial_floats = splitk_floats;
-        launch_conv_igemm(p, cfg, stream);
+        if (launch_conv_igemm(p, cfg, stream) != 0) ++conv_errors;
     }
 };
 
@@ -1287,6 +1288,7 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
         }
+        if (c.conv_errors) return fail(CCVPE_EINVAL, "%d convolution launches were refused (unsupported geometry)", c.conv_errors);
         done += mb;
     }
     hipError_t e = hipGetLastError();
