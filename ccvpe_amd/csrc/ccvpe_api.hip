@@ -139,7 +139,11 @@ struct DecoderW {
     int l1_cx = 0, l1_cxp = 0;
 };
 
-struct Tensor { int id = -1; int B = 0, H = 0, W = 0, C = 0; };
+struct Tensor {
+    int id = -1; int B = 0, H = 0, W = 0, C = 0;
+    bool split = false;   // bf16x3 mode: stored as two bf16 planes (hi | lo) instead of fp32
+    long long numel() const { return (long long)B * H * W * C; }
+};
 
 struct Ctx {
     float* arena = nullptr;
@@ -153,6 +157,7 @@ struct Ctx {
     const float* cache_in = nullptr;   // aerial cache consumed by a "cached" plan
     float* cache_out = nullptr;        // aerial cache produced by an "encode" plan
     float* ptr(const Tensor& t) const { return arena + (*off)[t.id]; }
+    Dst dst(const Tensor& t, int coff = 0) const { return Dst{ptr(t), t.C, coff, t.split ? 1 : 0, t.numel()}; }
     mutable int conv_errors = 0;   // launches refused by launch_conv_igemm (unsupported geometry)
     void launch_conv(ConvParams& p, int cfg) const {
         p.partial = splitk_scratch;
@@ -169,6 +174,7 @@ struct Op {
     // implicit-GEMM launches: tile id the launch uses (0 = heuristic) - set by Plan::autotune
     std::shared_ptr<int> tile;
     int gemm_m = 0, gemm_n = 0, gemm_kpad = 0;
+    bool bf16x3_only = false;     // the launch reads a pre-split bf16 tensor: exact-fp32 tiles cannot serve it
 };
 
 struct TapInfo { Tensor t; int coff; int C; };
@@ -640,7 +646,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
                 p.gate = c.ptr(gate);
                 if (skip) { p.resid = c.ptr(xin); p.resid_ld = xin.C; }
                 p.dst[0] = {c.ptr(o), o.C, 0}; p.ndst = 1;
-                for (int t = 0; t < td.n; ++t) p.dst[p.ndst++] = {c.ptr(td.t[t]), td.t[t].C, td.coff[t]};
+                for (int t = 0; t < td.n; ++t) p.dst[p.ndst++] = c.dst(td.t[t], td.coff[t]);
                 c.launch_conv(p, tile);
             }, 2.0 * B * oh * ow * mid * b.cout, 4.0 * B * oh * ow * (mid + b.cout * (1 + td.n)));
         }
@@ -717,6 +723,9 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
         loc_in[j] = pl.alloc(B, hw_in, hw_in, 8 + vs.match_ch[j]);
         loc_cat[j] = pl.alloc(B, hw_in * 2, hw_in * 2, vs.loc[j].dout + vs.loc[j].skip);
         ori_cat[j] = pl.alloc(B, hw_in * 2, hw_in * 2, vs.ori[j].dout + vs.ori[j].skip);
+        // bf16x3 mode: tensors consumed only by convolutions live as pre-split bf16 planes (same bytes), so the
+        // consumers' K loops carry no fp32->bf16 conversion; level 1 (j == 5) feeds the fp32 tail and stays fp32
+        if (h->cfg.reserved[0] == 1 && j < 5) { loc_cat[j].split = true; ori_cat[j].split = true; }
     }
     ori_in6 = pl.alloc(B, 8, 8, rpad + D);
 
@@ -741,7 +750,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
             const int C = TAP_C[t];
             const long long P = (long long)B * TAP_HW[t];
             pl.add("sat.cached_tap" + std::to_string(TAP_BLOCK[t]), {lc, oc}, [=](const Ctx& c) {
-                launch_scatter_channels(c.cache_in + src_off, C, P, Dst{c.ptr(lc), lc.C, lcoff}, Dst{c.ptr(oc), oc.C, ocoff}, 2, c.stream);
+                launch_scatter_channels(c.cache_in + src_off, C, P, c.dst(lc, lcoff), c.dst(oc, ocoff), 2, c.stream);
             }, 0, 4.0 * P * C * 3);
         }
     }
@@ -775,7 +784,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
         Tensor dm = dmap;
         const long long P = (long long)B * 64;
         pl.add("sat.cached_descmap", {dm}, [=](const Ctx& c) {
-            launch_scatter_channels(c.cache_in, D, P, Dst{c.ptr(dm), D, 0}, Dst{nullptr, 0, 0}, 1, c.stream);
+            launch_scatter_channels(c.cache_in, D, P, c.dst(dm), Dst{nullptr, 0, 0, 0, 0}, 1, c.stream);
         }, 0, 8.0 * P * D);
         pl.taps["sat_descriptor_map"] = {dmap, 0, D};
     } else {
@@ -799,18 +808,21 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
             pl.add_conv(tag + ".deconv", {din, cat}, B * hin * hin, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(din), din.C, B, hin, hin, hin, hin, 1, 0, 0, ACT_NONE);
                 p.mode = MODE_DECONV; p.deconv_cout = cout;
-                p.dst[0] = {c.ptr(cat), cat.C, 0}; p.ndst = 1;
+                p.dst[0] = c.dst(cat); p.ndst = 1;
                 c.launch_conv(p, tile);
             }, 2.0 * B * hin * hin * (double)l.din * 4 * l.dout, 4.0 * B * hin * hin * ((double)din.C + 4.0 * l.dout));
         }
         Tensor mid = pl.alloc(B, hout, hout, l.mid);
+        mid.split = cat.split;   // bf16x3 mode: conv_a -> conv_b hand-off stays in split bf16 form
         {
             const PackedConv* pc = &dw.conva[j];
             pl.add_conv(tag + ".conv_a", {cat, mid}, B * hout * hout, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(cat), cat.C, B, hout, hout, hout, hout, 1, 1, 1, ACT_RELU);
-                p.dst[0] = {c.ptr(mid), mid.C, 0}; p.ndst = 1;
+                p.in_split = cat.split; p.in_plane_bytes = (unsigned)(cat.numel() * 2);
+                p.dst[0] = c.dst(mid); p.ndst = 1;
                 c.launch_conv(p, tile);
             }, 2.0 * B * hout * hout * 9.0 * cat.C * l.mid, 4.0 * B * hout * hout * ((double)cat.C + l.mid));
+            pl.ops.back().bf16x3_only = cat.split;
         }
         if (j == 5) return mid;   // tail conv handled by the caller
         Tensor o = pl.alloc(B, hout, hout, l.out);
@@ -818,9 +830,11 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
             const PackedConv* pc = &dw.convb[j];
             pl.add_conv(tag + ".conv_b", {mid, o}, B * hout * hout, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(mid), mid.C, B, hout, hout, hout, hout, 1, 1, 1, ACT_NONE);
+                p.in_split = mid.split; p.in_plane_bytes = (unsigned)(mid.numel() * 2);
                 p.dst[0] = {c.ptr(o), o.C, 0}; p.ndst = 1;
                 c.launch_conv(p, tile);
             }, 2.0 * B * hout * hout * 9.0 * l.mid * l.out, 4.0 * B * hout * hout * ((double)l.mid + l.out));
+            pl.ops.back().bf16x3_only = mid.split;
         }
         return o;
     };
@@ -1127,6 +1141,7 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
         for (int t = 1; t <= nt; ++t) {
             if (conv_igemm_tile_util(q, t) < 0.45) continue;
             if (conv_igemm_tile_is_bf16x3(t) && h->cfg.reserved[0] != 1) continue;
+            if (op.bf16x3_only && !conv_igemm_tile_is_bf16x3(t)) continue;
             const long long blocks = conv_igemm_tile_blocks(q, t);
             for (int split = 1; split <= 16; split *= 2) {
                 if (split > 1) {   // split-K only where the grid underfills the chip and K is deep enough

@@ -61,8 +61,21 @@ __device__ __forceinline__ void emit_out4(const ConvParams& p, int m, int n, f32
     if (p.vec_epi) {
         if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.resid_ld + n);
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
-            if (d < p.ndst) *reinterpret_cast<f32x4*>(p.dst[d].ptr + (size_t)opix * p.dst[d].ld + p.dst[d].coff + o) = v;
+        for (int d = 0; d < 3; ++d) {
+            if (d >= p.ndst) continue;
+            const size_t e = (size_t)opix * p.dst[d].ld + p.dst[d].coff + o;
+            if (p.dst[d].split) {   // bf16x3 mode: hi = bf16(v), lo = bf16(v - hi), one plane each
+                typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                bf16x4_t h, l;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { h[k] = (__bf16)v[k]; l[k] = (__bf16)(v[k] - (float)h[k]); }
+                __bf16* hp = reinterpret_cast<__bf16*>(p.dst[d].ptr);
+                *reinterpret_cast<bf16x4_t*>(hp + e) = h;
+                *reinterpret_cast<bf16x4_t*>(hp + p.dst[d].plane + e) = l;
+            } else {
+                *reinterpret_cast<f32x4*>(p.dst[d].ptr + e) = v;
+            }
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

@@ -12,6 +12,9 @@ struct Dst {
     float* ptr;
     int ld;
     int coff;
+    // split != 0: the tensor is stored as two bf16 planes (bf16x3 mode): hi at ptr, lo `plane` bf16 elements later
+    int split;
+    long long plane;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -46,6 +49,8 @@ struct ConvParams {
     int deconv_cout;
     int M;                     // B*OH*OW
     unsigned in_bytes;         // extent of `in` for the bounds-checked buffer loads (< 2 GiB)
+    int in_split;              // input is a split bf16 tensor (hi plane | lo plane); bf16x3 tiles only
+    unsigned in_plane_bytes;   // byte distance between the two planes
     unsigned gate_bytes;
     // filled by launch_conv_igemm (conv_igemm_prepare): K-order arithmetic, see chunk_to_tap()
     int taps4;                 // 4 * KH*KW

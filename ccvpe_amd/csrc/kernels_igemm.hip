@@ -415,10 +415,16 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
     if (p.KH * p.KW > 16 || p.Cin % 8 || conv_igemm_prepare(p) != 0) return -1;   // geometry outside the supported range
     p.vec_epi = (p.N % 4 == 0) && (p.resid == nullptr || p.resid_ld % 4 == 0) && (p.mode != MODE_DECONV || p.deconv_cout % 4 == 0);
     for (int d = 0; d < p.ndst; ++d) p.vec_epi = p.vec_epi && p.dst[d].ld % 4 == 0 && p.dst[d].coff % 4 == 0;
+    for (int d = 0; d < p.ndst; ++d)
+        if (p.dst[d].split && !p.vec_epi) return -1;   // split destinations exist only on the 16-byte path
     int splitk = (tile >> 8) & 0xff;
     tile &= 0xff;
     if (conv_igemm_tile_is_bf16x3(tile) && (p.w_hi == nullptr || p.w_lo == nullptr)) tile = 0;   // planes not packed: fp32 path
     if (tile < 1 || tile > NTILES + bf16x3_num_tiles()) tile = pick_tile(p);
+    if (p.in_split) {   // pre-split bf16 input: only the bf16x3 kernels can read it
+        if (p.w_hi == nullptr) return -1;
+        if (!conv_igemm_tile_is_bf16x3(tile)) tile = NTILES + 3;   // conv_bf16x3_64x64_m32: valid for any shape
+    }
     if (splitk < 2 || p.partial == nullptr || (size_t)splitk * p.M * p.N > p.partial_floats) splitk = 1;
     p.splitk = splitk;
     g_last_tile = tile | (splitk << 8);

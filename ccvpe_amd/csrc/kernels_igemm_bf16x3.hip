@@ -42,7 +42,10 @@ template <> struct MfmaB<16> {
 // byte offset of 16-byte chunk `ch` (0..3) of row `r` in a swizzled [rows][32 bf16] image
 __device__ __forceinline__ int swz(int r, int ch) { return r * 64 + ((ch ^ ((r >> 2) & 3)) << 4); }
 
-template <int BM, int BN, int WGM, int WGN, int MT, bool GATE>
+// SPLIT: the activation already lives in HBM as two bf16 planes (hi at p.in, lo at p.in + in_plane elements of
+// bf16) written by the producing layer's epilogue - the K loop then carries no conversion VALU at all (with fp32
+// inputs the split costs ~5 VALU instructions per MFMA and the kernel is VALU-issue bound).
+template <int BM, int BN, int WGM, int WGN, int MT, bool GATE, bool SPLIT>
 __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams p) {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -50,6 +53,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
     static_assert(TM >= 1 && TN >= 1 && TM * MT * WGM == BM && TN * MT * WGN == BN, "tile must be whole MFMA tiles");
     constexpr int AR = BM / 32;          // float4 rows each thread stages for A (8 threads per 32-float row)
     constexpr int BRH = (BN + 63) / 64;  // 16-byte rows each thread stages per weight plane (4 threads per row)
+    constexpr int ARS = (BM + 63) / 64;  // SPLIT: 16-byte rows each thread stages per activation plane
+    static_assert(!(GATE && SPLIT), "pre-split activations carry no squeeze-excite gate");
     using M = MfmaB<MT>;
     using acc_t = typename M::acc_t;
 
@@ -65,6 +70,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
     const int kq = tid & 7;
     const int r0 = tid >> 3;
 
+    // SPLIT: one descriptor over both planes (hi | lo), element size 2 bytes
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t gate_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE ? p.gate : p.in), 0, GATE ? p.gate_bytes : 0, 0x00020000);
@@ -88,8 +94,26 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
         a_ix[j] = ix0;
         a_gb[j] = (b * p.Cin + (kq & 1) * 4) * 4;
     }
-    // weight planes: thread -> (row = tid>>2 (+64j), 16-byte chunk = tid&3)
+    // weight planes (and SPLIT activation planes): thread -> (row = tid>>2 (+64j), 16-byte chunk = tid&3)
     const int wch = tid & 3, wr0 = tid >> 2;
+    int s_base[ARS], s_iy[ARS], s_ix[ARS];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int j = 0; j < ARS; ++j) {
+            const int m = m0 + wr0 + 64 * j;
+            const bool ok = (m < p.M) && (BM % 64 == 0 || wr0 + 64 * j < BM);
+            const int mm = ok ? m : 0;
+            const int b = mm / ohw;
+            const int rem = mm - b * ohw;
+            const int oy = rem / p.OW;
+            const int ox = rem - oy * p.OW;
+            const int iy0 = oy * p.stride - p.pad_t;
+            const int ix0 = ox * p.stride - p.pad_l;
+            s_base[j] = (((b * p.H + iy0) * p.W + ix0) * p.in_ld) * 2;   // bytes inside a bf16 plane
+            s_iy[j] = ok ? iy0 : -(1 << 28);
+            s_ix[j] = ix0;
+        }
+    }
     const unsigned short* wrow_h[BRH];
     const unsigned short* wrow_l[BRH];
 #pragma unroll
@@ -102,23 +126,41 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
     f32x4 ra[AR];
     f32x4 rg[GATE ? AR : 1];
     u32x4 rbh[BRH], rbl[BRH];
+    u32x4 rah[SPLIT ? ARS : 1], ral[SPLIT ? ARS : 1];
 
 #define CCVPE_LOAD_TILE(kt)                                                                              \
     {                                                                                                    \
-        const int g = (kt) * 4 + (kq >> 1);                                                              \
-        int tap, c0;                                                                                     \
-        chunk_to_tap(p, g, tap, c0);                                                                     \
-        const int ky = (tap * p.div_kw_mul) >> 5;                                                        \
-        const int kx = tap - ky * p.KW;                                                                  \
-        const bool gok = g < p.nchunks;                                                                  \
-        const int koff = ((ky * p.W + kx) * p.in_ld + c0) * 4;                                           \
-        _Pragma("unroll") for (int j = 0; j < AR; ++j) {                                                 \
-            const int iy = a_iy[j] + ky, ix = a_ix[j] + kx;                                              \
-            const bool ok = gok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);       \
-            const unsigned off = ok ? (unsigned)(a_base[j] + koff) : OOB;                                \
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0)); \
-            if (GATE) {                                                                                  \
-                rg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gate_rsrc, ok ? (unsigned)(a_gb[j] + c0 * 4) : OOB, 0, 0)); \
+        if constexpr (SPLIT) {                                                                           \
+            const int g = (kt) * 4 + wch;                                                                \
+            int tap, c0;                                                                                 \
+            chunk_to_tap(p, g, tap, c0);                                                                 \
+            const int ky = (tap * p.div_kw_mul) >> 5;                                                    \
+            const int kx = tap - ky * p.KW;                                                              \
+            const bool gok = g < p.nchunks;                                                              \
+            const int koff = ((ky * p.W + kx) * p.in_ld + c0) * 2;                                       \
+            _Pragma("unroll") for (int j = 0; j < ARS; ++j) {                                            \
+                const int iy = s_iy[j] + ky, ix = s_ix[j] + kx;                                          \
+                const bool ok = gok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);   \
+                const unsigned off = ok ? (unsigned)(s_base[j] + koff) : OOB;                            \
+                rah[j] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);                      \
+                ral[j] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off + p.in_plane_bytes : OOB, 0, 0); \
+            }                                                                                            \
+        } else {                                                                                         \
+            const int g = (kt) * 4 + (kq >> 1);                                                          \
+            int tap, c0;                                                                                 \
+            chunk_to_tap(p, g, tap, c0);                                                                 \
+            const int ky = (tap * p.div_kw_mul) >> 5;                                                    \
+            const int kx = tap - ky * p.KW;                                                              \
+            const bool gok = g < p.nchunks;                                                              \
+            const int koff = ((ky * p.W + kx) * p.in_ld + c0) * 4;                                       \
+            _Pragma("unroll") for (int j = 0; j < AR; ++j) {                                             \
+                const int iy = a_iy[j] + ky, ix = a_ix[j] + kx;                                          \
+                const bool ok = gok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);   \
+                const unsigned off = ok ? (unsigned)(a_base[j] + koff) : OOB;                            \
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0)); \
+                if (GATE) {                                                                              \
+                    rg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gate_rsrc, ok ? (unsigned)(a_gb[j] + c0 * 4) : OOB, 0, 0)); \
+                }                                                                                        \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int j = 0; j < BRH; ++j) {                                                \
@@ -129,18 +171,28 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
 #define CCVPE_STORE_TILE(stage)                                                                          \
     {                                                                                                    \
         unsigned char* sb = smem_b + (stage) * STAGE;                                                    \
-        _Pragma("unroll") for (int j = 0; j < AR; ++j) {                                                 \
-            f32x4 v_ = ra[j];                                                                            \
-            if (GATE) v_ *= rg[j];                                                                       \
-            bf16x4 h_, l_;                                                                               \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                              \
-                h_[e] = (__bf16)v_[e];                                                                   \
-                l_[e] = (__bf16)(v_[e] - (float)h_[e]);                                                  \
+        if constexpr (SPLIT) {                                                                           \
+            _Pragma("unroll") for (int j = 0; j < ARS; ++j) {                                            \
+                const int r_ = wr0 + 64 * j;                                                             \
+                if (BM % 64 == 0 || r_ < BM) {                                                           \
+                    *reinterpret_cast<u32x4*>(sb + swz(r_, wch)) = rah[j];                               \
+                    *reinterpret_cast<u32x4*>(sb + BM * 64 + swz(r_, wch)) = ral[j];                     \
+                }                                                                                        \
             }                                                                                            \
-            const int r_ = r0 + 32 * j;                                                                  \
-            const int o_ = swz(r_, kq >> 1) + (kq & 1) * 8;                                              \
-            *reinterpret_cast<bf16x4*>(sb + o_) = h_;                                                    \
-            *reinterpret_cast<bf16x4*>(sb + BM * 64 + o_) = l_;                                          \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < AR; ++j) {                                             \
+                f32x4 v_ = ra[j];                                                                        \
+                if (GATE) v_ *= rg[j];                                                                   \
+                bf16x4 h_, l_;                                                                           \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                          \
+                    h_[e] = (__bf16)v_[e];                                                               \
+                    l_[e] = (__bf16)(v_[e] - (float)h_[e]);                                              \
+                }                                                                                        \
+                const int r_ = r0 + 32 * j;                                                              \
+                const int o_ = swz(r_, kq >> 1) + (kq & 1) * 8;                                          \
+                *reinterpret_cast<bf16x4*>(sb + o_) = h_;                                                \
+                *reinterpret_cast<bf16x4*>(sb + BM * 64 + o_) = l_;                                      \
+            }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int j = 0; j < BRH; ++j) {                                                \
             const int r_ = wr0 + 64 * j;                                                                 \
@@ -251,13 +303,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int MT, bool GATE>
+template <int BM, int BN, int WGM, int WGN, int MT, bool GATE, bool SPLIT>
 static void launch_b2(const ConvParams& p, hipStream_t s) {
     constexpr size_t stage_bytes = 2 * (size_t)(2 * BM + 2 * BN) * 64;
     constexpr size_t c_bytes = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds = stage_bytes > c_bytes ? stage_bytes : c_bytes;
     static bool attr_done = false;
-    auto kern = conv_igemm_bf16x3_kernel<BM, BN, WGM, WGN, MT, GATE>;
+    auto kern = conv_igemm_bf16x3_kernel<BM, BN, WGM, WGN, MT, GATE, SPLIT>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
@@ -269,8 +321,9 @@ static void launch_b2(const ConvParams& p, hipStream_t s) {
 
 template <int BM, int BN, int WGM, int WGN, int MT>
 static void launch_b(const ConvParams& p, hipStream_t s) {
-    if (p.gate) launch_b2<BM, BN, WGM, WGN, MT, true>(p, s);
-    else launch_b2<BM, BN, WGM, WGN, MT, false>(p, s);
+    if (p.in_split) launch_b2<BM, BN, WGM, WGN, MT, false, true>(p, s);
+    else if (p.gate) launch_b2<BM, BN, WGM, WGN, MT, true, false>(p, s);
+    else launch_b2<BM, BN, WGM, WGN, MT, false, false>(p, s);
 }
 
 static const Bf16x3Tile BF16X3_TILES_[] = {

@@ -212,6 +212,22 @@ void launch_preprocess(const PreprocParams& p, hipStream_t s) {
     hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, s, p);
 }
 
+__device__ __forceinline__ void put4(const Dst& d, long long pix, int c, float4 v) {
+    const size_t e = (size_t)pix * d.ld + d.coff + c;
+    if (d.split) {   // bf16x3 mode: two bf16 planes
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        bf16x4_t h, l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { h[k] = (__bf16)f[k]; l[k] = (__bf16)(f[k] - (float)h[k]); }
+        __bf16* hp = reinterpret_cast<__bf16*>(d.ptr);
+        *reinterpret_cast<bf16x4_t*>(hp + e) = h;
+        *reinterpret_cast<bf16x4_t*>(hp + d.plane + e) = l;
+    } else {
+        *reinterpret_cast<float4*>(d.ptr + e) = v;
+    }
+}
+
 // contiguous [P][C] -> channel window of an NHWC buffer (cached aerial taps -> decoder concat buffers)
 __global__ __launch_bounds__(256) void scatter_channels_kernel(const float* src, int C, long long P, Dst d0, Dst d1, int ndst) {
     const int c4n = C >> 2;
@@ -220,8 +236,8 @@ __global__ __launch_bounds__(256) void scatter_channels_kernel(const float* src,
         const long long pix = i / c4n;
         const int c4 = (int)(i - pix * c4n);
         const float4 v = *reinterpret_cast<const float4*>(src + pix * C + c4 * 4);
-        *reinterpret_cast<float4*>(d0.ptr + pix * d0.ld + d0.coff + c4 * 4) = v;
-        if (ndst > 1) *reinterpret_cast<float4*>(d1.ptr + pix * d1.ld + d1.coff + c4 * 4) = v;
+        put4(d0, pix, c4 * 4, v);
+        if (ndst > 1) put4(d1, pix, c4 * 4, v);
     }
 }
 
