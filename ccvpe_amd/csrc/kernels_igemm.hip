@@ -189,6 +189,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     acc[i][j] = M::run(a[cur][i].w, b[cur][j].w, acc[i][j]);
                 }
         }
+        // ... and the LDS stores (which wait for those loads) BELOW it
+        __builtin_amdgcn_sched_barrier(0);
         CCVPE_STORE_TILE(stage ^ 1);
         __syncthreads();
     }

@@ -39,8 +39,15 @@ template <> struct MfmaB<16> {
     static __device__ __forceinline__ int chunk(int, int lane) { return lane >> 4; }
 };
 
-// byte offset of 16-byte chunk `ch` (0..3) of row `r` in a swizzled [rows][32 bf16] image
-__device__ __forceinline__ int swz(int r, int ch) { return r * 64 + ((ch ^ ((r >> 2) & 3)) << 4); }
+// byte offset of 16-byte chunk `ch` (0..3) of row `r` in a swizzled [rows][32 bf16] image (4 rows per 256-B bank
+// row).  A ds_read_b128 is served in 16-lane groups {0-3,12-15,20-27}, ...: for the 32x32x16 fragment a group reads
+// 16 rows at ONE chunk -> XOR with (r>>2)&3 spreads them; for the 16x16x32 fragment a group reads rows 0-3 and
+// 12-15 at chunk c and rows 4-11 at chunk c+1 -> rotate by 2 for rows 8-15 instead (XOR would collide 2-way).
+template <int MT>
+__device__ __forceinline__ int swz(int r, int ch) {
+    if (MT == 32) return r * 64 + ((ch ^ ((r >> 2) & 3)) << 4);
+    return r * 64 + (((ch + ((r >> 3) & 1) * 2) & 3) << 4);
+}
 
 // SPLIT: the activation already lives in HBM as two bf16 planes (hi at p.in, lo at p.in + in_plane elements of
 // bf16) written by the producing layer's epilogue - the K loop then carries no conversion VALU at all (with fp32
@@ -175,8 +182,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
             _Pragma("unroll") for (int j = 0; j < ARS; ++j) {                                            \
                 const int r_ = wr0 + 64 * j;                                                             \
                 if (BM % 64 == 0 || r_ < BM) {                                                           \
-                    *reinterpret_cast<u32x4*>(sb + swz(r_, wch)) = rah[j];                               \
-                    *reinterpret_cast<u32x4*>(sb + BM * 64 + swz(r_, wch)) = ral[j];                     \
+                    *reinterpret_cast<u32x4*>(sb + swz<MT>(r_, wch)) = rah[j];                               \
+                    *reinterpret_cast<u32x4*>(sb + BM * 64 + swz<MT>(r_, wch)) = ral[j];                     \
                 }                                                                                        \
             }                                                                                            \
         } else {                                                                                         \
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
                     l_[e] = (__bf16)(v_[e] - (float)h_[e]);                                              \
                 }                                                                                        \
                 const int r_ = r0 + 32 * j;                                                              \
-                const int o_ = swz(r_, kq >> 1) + (kq & 1) * 8;                                          \
+                const int o_ = swz<MT>(r_, kq >> 1) + (kq & 1) * 8;                                          \
                 *reinterpret_cast<bf16x4*>(sb + o_) = h_;                                                \
                 *reinterpret_cast<bf16x4*>(sb + BM * 64 + o_) = l_;                                      \
             }                                                                                            \
@@ -197,8 +204,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
         _Pragma("unroll") for (int j = 0; j < BRH; ++j) {                                                \
             const int r_ = wr0 + 64 * j;                                                                 \
             if (BN % 64 == 0 || r_ < BN) {                                                               \
-                *reinterpret_cast<u32x4*>(sb + 2 * BM * 64 + swz(r_, wch)) = rbh[j];                     \
-                *reinterpret_cast<u32x4*>(sb + 2 * BM * 64 + BN * 64 + swz(r_, wch)) = rbl[j];           \
+                *reinterpret_cast<u32x4*>(sb + 2 * BM * 64 + swz<MT>(r_, wch)) = rbh[j];                     \
+                *reinterpret_cast<u32x4*>(sb + 2 * BM * 64 + BN * 64 + swz<MT>(r_, wch)) = rbl[j];           \
             }                                                                                            \
         }                                                                                                \
     }
@@ -240,13 +247,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int o = swz(a_row + i * MT, ch);
+                const int o = swz<MT>(a_row + i * MT, ch);
                 ah[i] = *reinterpret_cast<const bf16x8*>(sb + o);
                 al[i] = *reinterpret_cast<const bf16x8*>(sb + BM * 64 + o);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int o = swz(b_row + j * MT, ch);
+                const int o = swz<MT>(b_row + j * MT, ch);
                 bh[j] = *reinterpret_cast<const bf16x8*>(sb + 2 * BM * 64 + o);
                 bl[j] = *reinterpret_cast<const bf16x8*>(sb + 2 * BM * 64 + BN * 64 + o);
             }
@@ -259,6 +266,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
                     acc[i][j] = M::run(ah[i], bh[j], acc[i][j]);
                 }
         }
+        // ... and the LDS stores (which wait for those loads) BELOW it
+        __builtin_amdgcn_sched_barrier(0);
         CCVPE_STORE_TILE(stage ^ 1);
         __syncthreads();
     }
