@@ -551,6 +551,7 @@ static ConvParams conv_params(const PackedConv& pc, const float* in, int in_ld, 
     p.M = B * OH * OW;
     p.in_bytes = (unsigned)((size_t)B * H * W * in_ld * sizeof(float));
     p.gate_bytes = (unsigned)((size_t)B * pc.cinp * sizeof(float));
+    p.w_plane_bytes = (unsigned)((size_t)p.Npad * pc.Kpad * sizeof(unsigned short));
     return p;
 }
 

@@ -51,6 +51,7 @@ struct ConvParams {
     unsigned in_bytes;         // extent of `in` for the bounds-checked buffer loads (< 2 GiB)
     int in_split;              // input is a split bf16 tensor (hi plane | lo plane); bf16x3 tiles only
     unsigned in_plane_bytes;   // byte distance between the two planes
+    unsigned w_plane_bytes;    // extent of one bf16 weight plane (Npad*Kpad*2)
     unsigned gate_bytes;
     // filled by launch_conv_igemm (conv_igemm_prepare): K-order arithmetic, see chunk_to_tap()
     int taps4;                 // 4 * KH*KW

@@ -20,6 +20,7 @@ namespace ccvpe {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* LdsPtr;
 
 template <int MT> struct MfmaB;
 template <> struct MfmaB<32> {
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
     static_assert(TM >= 1 && TN >= 1 && TM * MT * WGM == BM && TN * MT * WGN == BN, "tile must be whole MFMA tiles");
     constexpr int AR = BM / 32;          // float4 rows each thread stages for A (8 threads per 32-float row)
     constexpr int BRH = (BN + 63) / 64;  // 16-byte rows each thread stages per weight plane (4 threads per row)
-    constexpr int ARS = (BM + 63) / 64;  // SPLIT: 16-byte rows each thread stages per activation plane
+    static_assert(!SPLIT || (BM % 64 == 0 && BN % 16 == 0), "LDS-DMA staging copies whole 16-row blocks");
     static_assert(!(GATE && SPLIT), "pre-split activations carry no squeeze-excite gate");
     using M = MfmaB<MT>;
     using acc_t = typename M::acc_t;
@@ -103,12 +104,20 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
     }
     // weight planes (and SPLIT activation planes): thread -> (row = tid>>2 (+64j), 16-byte chunk = tid&3)
     const int wch = tid & 3, wr0 = tid >> 2;
-    int s_base[ARS], s_iy[ARS], s_ix[ARS];
+    // SPLIT (LDS-DMA staging): wave w copies 16-row blocks w, w+4, ... of every plane straight into LDS with
+    // buffer_load_dwordx4 ... lds (no VGPR round trip, no ds_write): lane l fills row (l>>2), physical 16-byte
+    // slot (l&3) of its block, i.e. the logical chunk the swizzle maps there (the swizzle is an involution)
+    constexpr int ARD = BM / 64;             // A row blocks per wave (BM/16 blocks over 4 waves)
+    constexpr int BRD = (BN / 16 + 3) / 4;   // B row blocks per wave (upper bound)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int s_base[SPLIT ? ARD : 1], s_iy[SPLIT ? ARD : 1], s_ix[SPLIT ? ARD : 1], s_ch[SPLIT ? ARD : 1];
+    int w_off[SPLIT ? BRD : 1], w_ch[SPLIT ? BRD : 1];
     if constexpr (SPLIT) {
 #pragma unroll
-        for (int j = 0; j < ARS; ++j) {
-            const int m = m0 + wr0 + 64 * j;
-            const bool ok = (m < p.M) && (BM % 64 == 0 || wr0 + 64 * j < BM);
+        for (int j = 0; j < ARD; ++j) {
+            const int r = (wave_u + 4 * j) * 16 + (lane >> 2);
+            const int m = m0 + r;
+            const bool ok = m < p.M;
             const int mm = ok ? m : 0;
             const int b = mm / ohw;
             const int rem = mm - b * ohw;
@@ -119,8 +128,17 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
             s_base[j] = (((b * p.H + iy0) * p.W + ix0) * p.in_ld) * 2;   // bytes inside a bf16 plane
             s_iy[j] = ok ? iy0 : -(1 << 28);
             s_ix[j] = ix0;
+            s_ch[j] = (swz<MT>(r, lane & 3) >> 4) & 3;                   // logical chunk stored at this slot
+        }
+#pragma unroll
+        for (int j = 0; j < BRD; ++j) {
+            const int r = (wave_u + 4 * j) * 16 + (lane >> 2);
+            w_ch[j] = (swz<MT>(r, lane & 3) >> 4) & 3;
+            w_off[j] = (min(n0 + r, p.Npad - 1) * p.Kpad + w_ch[j] * 8) * 2;   // bytes inside a weight plane
         }
     }
+    const __amdgpu_buffer_rsrc_t wh_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w_hi), 0, SPLIT ? p.w_plane_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wl_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.w_lo), 0, SPLIT ? p.w_plane_bytes : 0, 0x00020000);
     const unsigned short* wrow_h[BRH];
     const unsigned short* wrow_l[BRH];
 #pragma unroll
@@ -133,26 +151,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
     f32x4 ra[AR];
     f32x4 rg[GATE ? AR : 1];
     u32x4 rbh[BRH], rbl[BRH];
-    u32x4 rah[SPLIT ? ARS : 1], ral[SPLIT ? ARS : 1];
 
 #define CCVPE_LOAD_TILE(kt)                                                                              \
     {                                                                                                    \
-        if constexpr (SPLIT) {                                                                           \
-            const int g = (kt) * 4 + wch;                                                                \
-            int tap, c0;                                                                                 \
-            chunk_to_tap(p, g, tap, c0);                                                                 \
-            const int ky = (tap * p.div_kw_mul) >> 5;                                                    \
-            const int kx = tap - ky * p.KW;                                                              \
-            const bool gok = g < p.nchunks;                                                              \
-            const int koff = ((ky * p.W + kx) * p.in_ld + c0) * 2;                                       \
-            _Pragma("unroll") for (int j = 0; j < ARS; ++j) {                                            \
-                const int iy = s_iy[j] + ky, ix = s_ix[j] + kx;                                          \
-                const bool ok = gok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);   \
-                const unsigned off = ok ? (unsigned)(s_base[j] + koff) : OOB;                            \
-                rah[j] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);                      \
-                ral[j] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off + p.in_plane_bytes : OOB, 0, 0); \
-            }                                                                                            \
-        } else {                                                                                         \
+        if constexpr (!SPLIT) {                                                                          \
             const int g = (kt) * 4 + (kq >> 1);                                                          \
             int tap, c0;                                                                                 \
             chunk_to_tap(p, g, tap, c0);                                                                 \
@@ -170,23 +172,45 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
                 }                                                                                        \
             }                                                                                            \
         }                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < BRH; ++j) {                                                \
-            rbh[j] = *reinterpret_cast<const u32x4*>(wrow_h[j] + (kt) * 32);                             \
-            rbl[j] = *reinterpret_cast<const u32x4*>(wrow_l[j] + (kt) * 32);                             \
+        if constexpr (!SPLIT) {                                                                          \
+            _Pragma("unroll") for (int j = 0; j < BRH; ++j) {                                            \
+                rbh[j] = *reinterpret_cast<const u32x4*>(wrow_h[j] + (kt) * 32);                         \
+                rbl[j] = *reinterpret_cast<const u32x4*>(wrow_l[j] + (kt) * 32);                         \
+            }                                                                                            \
+        }                                                                                                \
+    }
+// SPLIT: asynchronous global -> LDS copies of K tile `kt` into stage `st` (out-of-range offsets write zeros)
+#define CCVPE_DMA_TILE(kt, st)                                                                           \
+    {                                                                                                    \
+        unsigned char* sb_ = smem_b + (st) * STAGE;                                                      \
+        _Pragma("unroll") for (int j = 0; j < ARD; ++j) {                                                \
+            const int g = (kt) * 4 + s_ch[j];                                                            \
+            int tap, c0;                                                                                 \
+            chunk_to_tap(p, g, tap, c0);                                                                 \
+            const int ky = (tap * p.div_kw_mul) >> 5;                                                    \
+            const int kx = tap - ky * p.KW;                                                              \
+            const int iy = s_iy[j] + ky, ix = s_ix[j] + kx;                                              \
+            const bool ok = (g < p.nchunks) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W); \
+            const unsigned off = ok ? (unsigned)(s_base[j] + ((ky * p.W + kx) * p.in_ld + c0) * 2) : OOB; \
+            LdsPtr dh = (LdsPtr)(sb_ + (wave_u + 4 * j) * 1024);                                         \
+            LdsPtr dl = (LdsPtr)(sb_ + BM * 64 + (wave_u + 4 * j) * 1024);                               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, dh, 16, off, 0, 0, 0);                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, dl, 16, ok ? off + p.in_plane_bytes : OOB, 0, 0, 0); \
+        }                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < BRD; ++j) {                                                \
+            if (wave_u + 4 * j < BN / 16) {                                                              \
+                const unsigned off = (unsigned)(w_off[j] + (kt) * 64);                                   \
+                LdsPtr dh = (LdsPtr)(sb_ + 2 * BM * 64 + (wave_u + 4 * j) * 1024);                       \
+                LdsPtr dl = (LdsPtr)(sb_ + 2 * BM * 64 + BN * 64 + (wave_u + 4 * j) * 1024);             \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wh_rsrc, dh, 16, off, 0, 0, 0);                 \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wl_rsrc, dl, 16, off, 0, 0, 0);                 \
+            }                                                                                            \
         }                                                                                                \
     }
 #define CCVPE_STORE_TILE(stage)                                                                          \
     {                                                                                                    \
         unsigned char* sb = smem_b + (stage) * STAGE;                                                    \
-        if constexpr (SPLIT) {                                                                           \
-            _Pragma("unroll") for (int j = 0; j < ARS; ++j) {                                            \
-                const int r_ = wr0 + 64 * j;                                                             \
-                if (BM % 64 == 0 || r_ < BM) {                                                           \
-                    *reinterpret_cast<u32x4*>(sb + swz<MT>(r_, wch)) = rah[j];                               \
-                    *reinterpret_cast<u32x4*>(sb + BM * 64 + swz<MT>(r_, wch)) = ral[j];                     \
-                }                                                                                        \
-            }                                                                                            \
-        } else {                                                                                         \
+        if constexpr (!SPLIT) {                                                                          \
             _Pragma("unroll") for (int j = 0; j < AR; ++j) {                                             \
                 f32x4 v_ = ra[j];                                                                        \
                 if (GATE) v_ *= rg[j];                                                                   \
@@ -201,11 +225,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
                 *reinterpret_cast<bf16x4*>(sb + BM * 64 + o_) = l_;                                      \
             }                                                                                            \
         }                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < BRH; ++j) {                                                \
-            const int r_ = wr0 + 64 * j;                                                                 \
-            if (BN % 64 == 0 || r_ < BN) {                                                               \
-                *reinterpret_cast<u32x4*>(sb + 2 * BM * 64 + swz<MT>(r_, wch)) = rbh[j];                     \
-                *reinterpret_cast<u32x4*>(sb + 2 * BM * 64 + BN * 64 + swz<MT>(r_, wch)) = rbl[j];           \
+        if constexpr (!SPLIT) {                                                                          \
+            _Pragma("unroll") for (int j = 0; j < BRH; ++j) {                                            \
+                const int r_ = wr0 + 64 * j;                                                             \
+                if (BN % 64 == 0 || r_ < BN) {                                                           \
+                    *reinterpret_cast<u32x4*>(sb + 2 * BM * 64 + swz<MT>(r_, wch)) = rbh[j];             \
+                    *reinterpret_cast<u32x4*>(sb + 2 * BM * 64 + BN * 64 + swz<MT>(r_, wch)) = rbl[j];   \
+                }                                                                                        \
             }                                                                                            \
         }                                                                                                \
     }
@@ -227,9 +253,14 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
     }
     {
         const int kfirst = min(kt0, nkt_all - 1);
-        CCVPE_LOAD_TILE(kfirst);
+        if constexpr (SPLIT) {
+            CCVPE_DMA_TILE(kfirst, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            CCVPE_LOAD_TILE(kfirst);
+            CCVPE_STORE_TILE(0);
+        }
     }
-    CCVPE_STORE_TILE(0);
     __syncthreads();
 
     const int a_row = wm * WM + (lane % MT);
@@ -238,7 +269,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
     for (int kt = kt0; kt < kt1; ++kt) {
         const int stage = (kt - kt0) & 1;
         const int ktn = min(kt + 1, kt1 - 1);
-        CCVPE_LOAD_TILE(ktn);
+        if constexpr (SPLIT) {
+            // stage^1 was last read one barrier ago: the copies of the next K tile land while this tile's MFMAs run
+            if (kt + 1 < kt1) CCVPE_DMA_TILE(ktn, stage ^ 1);
+        } else {
+            CCVPE_LOAD_TILE(ktn);
+        }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sb = smem_b + stage * STAGE;
 #pragma unroll
@@ -268,11 +304,16 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(const ConvParams
         }
         // ... and the LDS stores (which wait for those loads) BELOW it
         __builtin_amdgcn_sched_barrier(0);
-        CCVPE_STORE_TILE(stage ^ 1);
+        if constexpr (SPLIT) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA copies have landed
+        } else {
+            CCVPE_STORE_TILE(stage ^ 1);
+        }
         __syncthreads();
     }
 #undef CCVPE_LOAD_TILE
 #undef CCVPE_STORE_TILE
+#undef CCVPE_DMA_TILE
 
     // ---- epilogue (as kernels_igemm.hip): C tile through LDS, 16-byte row stores ----
     constexpr int LDC = BN + 4;
