@@ -19,7 +19,7 @@ from . import spec
 
 try:
     from ._bn_calib import BN_CALIB
-except ImportError:  # before tools/calibrate_bn.py has been run
+except ImportError:  # before tests/calibrate_bn.py has been run
     BN_CALIB = {}
 
 

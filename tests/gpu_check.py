@@ -1,4 +1,4 @@
-"""Dev tool (GPU box): run the HIP forward with debug taps and compare every tap with the oracle."""
+"""Manual parity script (GPU box; lives under tests/ because it uses the oracle): run the HIP forward with debug taps and compare every tap with the oracle."""
 import os
 import sys
 import time
