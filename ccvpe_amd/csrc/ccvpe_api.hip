@@ -885,10 +885,11 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
         mp.cat_max_ld = 8 + C;
         mp.cat_all_ld = rpad + C;
         Tensor xin = x, lin = loc_in[k];
+        Tensor ggs = pl.alloc(B, 1, 1, 4 * C + 4);
         const bool first = (k == 0);
         const int goff = loff[k];
         const int R = mp.R;
-        std::vector<Tensor> uses = {xin, desc, lin};
+        std::vector<Tensor> uses = {xin, desc, lin, ggs};
         if (first) uses.push_back(ori_in6);
         pl.add("match" + std::to_string(k + 1), uses, [=](const Ctx& c) {
             MatchParams q = mp;
@@ -896,6 +897,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
             q.ms = c.out.matching_score[k];
             q.cat_max = c.ptr(lin);
             q.cat_all = first ? c.ptr(ori_in6) : nullptr;
+            q.gg_scratch = c.ptr(ggs);
             launch_match(q, c.stream);
         }, 4.0 * B * hw * (double)R * L[k], 4.0 * B * hw * (2.0 * C + R + 8));
         pl.taps["loc_in" + std::to_string(6 - k)] = {lin, 0, lin.C};

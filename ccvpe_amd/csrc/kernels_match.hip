@@ -116,6 +116,82 @@ __global__ __launch_bounds__(256) void match_kernel(const MatchParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-C form (levels 5-6: C = 32, 40, 80): one thread owns one pixel and keeps its C channels in
+// registers; the descriptor is rolled instead of x:  score_r = sum_j x[j] * gpad[(j - s_r) mod C], with gpad
+// (g zero padded to C) stored twice back to back so that gg[C - s_r + j], j = 0..C-1, is one contiguous,
+// wave-uniform run (scalar / broadcast loads).  When L < C the window norm uses the doubled 0/1 mask the same
+// way; when L == C it is the roll-invariant full norm.  x is read once, no LDS, no per-pixel modulo.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void match_prep_kernel(const MatchParams p, float* gg) {
+    // gg[b] = [ gpad | gpad | mask | mask | ||g|| ]  (4C + 1 floats per sample)
+    __shared__ float red[4];
+    const int b = blockIdx.x, C = p.C, L = p.L;
+    float* o = gg + (size_t)b * (4 * C + 4);
+    float gsq = 0.f;
+    for (int i = threadIdx.x; i < C; i += 256) {
+        const float v = i < L ? p.g[(size_t)b * p.g_ld + i] : 0.f;
+        o[i] = v; o[C + i] = v;
+        const float m = i < L ? 1.f : 0.f;
+        o[2 * C + i] = m; o[3 * C + i] = m;
+        gsq = fmaf(v, v, gsq);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gsq += __shfl_xor(gsq, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gsq;
+    __syncthreads();
+    if (threadIdx.x == 0) o[4 * C] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void match_small_kernel(const MatchParams p, const float* __restrict__ gg) {
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= p.HW) return;
+    const float* xg = p.x + ((size_t)b * p.HW + pix) * p.x_ld;
+    float x[C];
+#pragma unroll
+    for (int c4 = 0; c4 < C / 4; ++c4) {
+        const float4 v = *reinterpret_cast<const float4*>(xg + c4 * 4);
+        x[c4 * 4 + 0] = v.x; x[c4 * 4 + 1] = v.y; x[c4 * 4 + 2] = v.z; x[c4 * 4 + 3] = v.w;
+    }
+    float n2full = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) n2full = fmaf(x[j], x[j], n2full);
+    const float* gb = gg + (size_t)b * (4 * C + 4);
+    const float gnorm = gb[4 * C];
+    const bool full = p.L == C;
+    float best = -INFINITY;
+    for (int r = 0; r < p.R; ++r) {
+        const int base = C - p.shift[r];          // wave-uniform
+        const float* gr = gb + base;
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) dot = fmaf(x[j], gr[j], dot);
+        float n2 = n2full;
+        if (!full) {
+            const float* mr = gb + 2 * C + base;
+            n2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < C; ++j) n2 = fmaf(x[j] * x[j], mr[j], n2);
+        }
+        const float sc = dot / (sqrtf(n2) * gnorm);
+        if (p.ms) p.ms[((size_t)b * p.R + r) * p.HW + pix] = sc;
+        if ((p.inmax >> r) & 1u) best = fmaxf(best, sc);
+    }
+    const float inv = 1.f / fmaxf(sqrtf(n2full), 1e-12f);
+    float* o = p.cat_max + ((size_t)b * p.HW + pix) * p.cat_max_ld;
+    *reinterpret_cast<float4*>(o) = make_float4(best, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c4 = 0; c4 < C / 4; ++c4)
+        *reinterpret_cast<float4*>(o + 8 + c4 * 4) = make_float4(x[c4 * 4] * inv, x[c4 * 4 + 1] * inv, x[c4 * 4 + 2] * inv, x[c4 * 4 + 3] * inv);
+}
+
+bool match_small_supported(const MatchParams& p) {
+    return (p.C == 32 || p.C == 40 || p.C == 80) && p.cat_all == nullptr && p.cat_max != nullptr && p.x_ld % 4 == 0;
+}
+
 int match_pixels_per_block(int HW, int C) {
     int P = 256;
     while (P > 8 && (size_t)P * (C + 1) * 4 > 40 * 1024) P >>= 1;
@@ -124,6 +200,14 @@ int match_pixels_per_block(int HW, int C) {
 }
 
 void launch_match(const MatchParams& p, hipStream_t s) {
+    if (p.gg_scratch && match_small_supported(p)) {
+        hipLaunchKernelGGL(match_prep_kernel, dim3(p.B), dim3(256), 0, s, p, p.gg_scratch);
+        dim3 grid((p.HW + 255) / 256, p.B);
+        if (p.C == 32) hipLaunchKernelGGL(match_small_kernel<32>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
+        else if (p.C == 40) hipLaunchKernelGGL(match_small_kernel<40>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
+        else hipLaunchKernelGGL(match_small_kernel<80>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
+        return;
+    }
     size_t lds = ((size_t)p.P * (p.C + 1) + ((p.L + 3) & ~3) + (size_t)(p.R + 1) * p.P + 4) * sizeof(float);
     static size_t max_set = 0;
     if (lds > 64 * 1024 && lds > max_set) {
