@@ -16,42 +16,47 @@ __device__ __forceinline__ float swishf(float v) { return v / (1.f + __expf(-v))
 // 27 input taps are broadcast loads and the store is a fully coalesced 16 B/lane stream.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
-    __shared__ float ws[27 * 32];
-    __shared__ float bs[32];
-    for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = p.w[i];
-    if (threadIdx.x < 32) bs[threadIdx.x] = p.bias[threadIdx.x];
-    __syncthreads();
+    // The grid stride is a multiple of 8, so a thread keeps its channel group for the whole launch and
+    // holds its 27 x 4 weights in registers (the LDS broadcast reads were the bottleneck before).
+    const int cg = threadIdx.x & 7;
+    float4 w[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) w[i] = *reinterpret_cast<const float4*>(p.w + i * 32 + cg * 4);
+    const float4 bias = *reinterpret_cast<const float4*>(p.bias + cg * 4);
     const long long total = (long long)p.B * p.OH * p.OW * 8;
     for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
-        const int cg = (int)(it & 7);
         long long pix = it >> 3;
         const int ox = (int)(pix % p.OW);
         long long t = pix / p.OW;
         const int oy = (int)(t % p.OH);
         const int b = (int)(t / p.OH);
-        float4 acc = *reinterpret_cast<const float4*>(bs + cg * 4);
+        float4 acc = bias;
         const float* inb = p.in + (size_t)b * 3 * p.H * p.W;
+        const int plane = p.H * p.W;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * 2 - p.pad_t + ky;
-            if ((unsigned)iy >= (unsigned)p.H) continue;
+            const bool oky = (unsigned)iy < (unsigned)p.H;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 int ix = ox * 2 - p.pad_l + kx;
+                bool ok = oky;
                 if (p.circular) {
                     if (ix < 0) ix += p.W;
                     if (ix >= p.W) ix -= p.W;
-                } else if ((unsigned)ix >= (unsigned)p.W) {
-                    continue;
+                } else {
+                    ok = ok & ((unsigned)ix < (unsigned)p.W);
                 }
+                const int o = ok ? iy * p.W + ix : 0;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float v = inb[((size_t)c * p.H + iy) * p.W + ix];
-                    const float4 w = *reinterpret_cast<const float4*>(ws + ((c * 3 + ky) * 3 + kx) * 32 + cg * 4);
-                    acc.x = fmaf(v, w.x, acc.x);
-                    acc.y = fmaf(v, w.y, acc.y);
-                    acc.z = fmaf(v, w.z, acc.z);
-                    acc.w = fmaf(v, w.w, acc.w);
+                    float v = inb[c * plane + o];
+                    v = ok ? v : 0.f;
+                    const float4 wv = w[(c * 3 + ky) * 3 + kx];
+                    acc.x = fmaf(v, wv.x, acc.x);
+                    acc.y = fmaf(v, wv.y, acc.y);
+                    acc.z = fmaf(v, wv.z, acc.z);
+                    acc.w = fmaf(v, wv.w, acc.w);
                 }
             }
         }

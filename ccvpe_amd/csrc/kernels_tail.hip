@@ -150,10 +150,26 @@ __global__ __launch_bounds__(1024) void postprocess_kernel(const float* heat, co
     const float* h = heat + (size_t)b * n;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const float v = h[i];
-        if (v > best) { best = v; bi = i; }   // strictly greater keeps the first index per thread
+    // strictly greater keeps the first index per thread; 4 independent 16-byte loads in flight per round
+    const int n4 = ((reinterpret_cast<uintptr_t>(h) & 15) == 0) ? (n >> 2) : 0;
+    const float4* h4 = reinterpret_cast<const float4*>(h);
+    auto take = [&](float v, int i) { if (v > best) { best = v; bi = i; } };
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = h4[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = (i + u * 1024) * 4;
+            take(v[u].x, e); take(v[u].y, e + 1); take(v[u].z, e + 2); take(v[u].w, e + 3);
+        }
     }
+    for (; i < n4; i += 1024) {
+        const float4 v = h4[i];
+        take(v.x, i * 4); take(v.y, i * 4 + 1); take(v.z, i * 4 + 2); take(v.w, i * 4 + 3);
+    }
+    for (int j = n4 * 4 + threadIdx.x; j < n; j += 1024) take(h[j], j);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float v2 = __shfl_xor(best, off);

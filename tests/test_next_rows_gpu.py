@@ -62,3 +62,27 @@ def test_cached_aerial_forward_equals_full_forward(name, batch):
     assert (a[0] - b[0]).abs().max().item() <= 2e-5 * a[0].abs().max().item()
     with pytest.raises(ValueError):
         m.forward_cached(g[:1].repeat(3, 1, 1, 1), cache)
+
+
+def test_postprocess_argmax_ties_take_the_first_index_like_numpy():
+    """train_VIGOR.py:300 uses np.argmax on the flattened heat map -> first maximal index on ties."""
+    m = models.CVM_OxfordRobotCar("cuda")
+    m.load_state_dict(weights.generate_state_dict("oxford", 0))
+    m.to("cuda").eval()
+    rng = np.random.default_rng(5)
+    B, n = 4, 512 * 512
+    heat = rng.random((B, 1, 512, 512), dtype=np.float32) * 0.5
+    flat = heat.reshape(B, n)
+    flat[0, [n - 1, 77777, 4099]] = 0.9          # three equal maxima, scattered over different threads
+    flat[1, [5, 4, 262143]] = 0.75               # neighbours inside one 16-byte load
+    flat[2, 0] = 0.99                            # very first element
+    flat[3, n - 1] = 0.99                        # very last element
+    ang = rng.uniform(-np.pi, np.pi, size=(B, 1, 512, 512)).astype(np.float32)
+    ori = np.concatenate([np.cos(ang), np.sin(ang)], axis=1)
+    post = m.postprocess(torch.from_numpy(heat).cuda(), torch.from_numpy(ori).cuda())
+    want = orc.postprocess(torch.from_numpy(heat), torch.from_numpy(ori))
+    idx = post["index"].cpu().numpy()
+    np.testing.assert_array_equal(idx, flat.argmax(axis=1))
+    np.testing.assert_array_equal(idx, [4099, 4, 0, n - 1])
+    np.testing.assert_array_equal(post["prob"].cpu().numpy(), flat.max(axis=1))
+    np.testing.assert_allclose(post["angle_deg"].cpu().numpy(), want[4].numpy(), rtol=1e-5, atol=1e-3)
