@@ -117,6 +117,9 @@ struct PackedConv {
     unsigned short *w_hi = nullptr, *w_lo = nullptr;   // bf16x3 planes (precision mode 1 only)
     float* bias = nullptr;
     int N = 0, Kpad = 0, nchunks = 0, cinp = 0, KH = 1, KW = 1;
+    float* wino = nullptr;        // Winograd-domain weights of a 3x3 layer (kernels_wino.hip), fp32 mode only
+    int wino_n16 = 0;
+    size_t wino_bytes = 0;
 };
 struct BlockW {
     PackedConv expand, project;
@@ -175,6 +178,7 @@ struct Op {
     std::shared_ptr<int> tile;
     int gemm_m = 0, gemm_n = 0, gemm_kpad = 0;
     bool bf16x3_only = false;     // the launch reads a pre-split bf16 tensor: exact-fp32 tiles cannot serve it
+    bool wino_ok = false;         // 3x3 / stride 1 layer with Winograd-domain weights packed
 };
 
 struct TapInfo { Tensor t; int coff; int C; };
@@ -269,6 +273,7 @@ struct ccvpe_handle_s {
     bool autotune = true;
     int fuse_mbconv = 1;          // CCVPE_FUSE_MBCONV: 0 never, 1 where measured profitable (3x3 blocks), 2 every supported block
     bool fuse_level1 = true;      // CCVPE_FUSE_L1=0 falls back to deconv / conv / tail launches
+    bool wino = true;             // CCVPE_WINOGRAD=0 keeps the decoder 3x3 layers on the implicit GEMM
     int graph_mode = -1;          // -1 auto (plans of <= 4 samples replay a hipGraph), 0 never, 1 always
     hipStream_t capture_stream = nullptr;
     std::vector<void*> dev_allocs;
@@ -361,6 +366,12 @@ static int pack_conv(ccvpe_handle_s* h, PackedConv& pc, int N, int taps, int cin
     pc.N = N; pc.Kpad = kpad; pc.nchunks = K / 8; pc.cinp = cinp; pc.KH = KH; pc.KW = KW;
     int rc = upload(h, w, &pc.w);
     if (rc) return rc;
+    if (KH == 3 && KW == 3 && cin == cinp && cin % 8 == 0 && (size_t)(cin / 8) * 16 * ((N + 15) / 16) * 512 < (1u << 31)) {
+        std::vector<float> u;
+        conv_wino_pack(N, cin, get, u, &pc.wino_n16);
+        pc.wino_bytes = u.size() * sizeof(float);
+        if ((rc = upload(h, u, &pc.wino))) return rc;
+    }
     if (h->cfg.reserved[0] == 1) {   // bf16x3: hi = bf16(w), lo = bf16(w - hi), round to nearest even
         auto to_bf16 = [](float f) -> unsigned short {
             uint32_t u; std::memcpy(&u, &f, 4);
@@ -552,6 +563,7 @@ static ConvParams conv_params(const PackedConv& pc, const float* in, int in_ld, 
     p.in_bytes = (unsigned)((size_t)B * H * W * in_ld * sizeof(float));
     p.gate_bytes = (unsigned)((size_t)B * pc.cinp * sizeof(float));
     p.w_plane_bytes = (unsigned)((size_t)p.Npad * pc.Kpad * sizeof(unsigned short));
+    p.wino_w = pc.wino; p.wino_n16 = pc.wino_n16; p.wino_bytes = (unsigned)pc.wino_bytes;
     return p;
 }
 
@@ -824,6 +836,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
                 c.launch_conv(p, tile);
             }, 2.0 * B * hout * hout * 9.0 * cat.C * l.mid, 4.0 * B * hout * hout * ((double)cat.C + l.mid));
             pl.ops.back().bf16x3_only = cat.split;
+            pl.ops.back().wino_ok = pc->wino != nullptr && !cat.split && h->wino;
         }
         if (j == 5) return mid;   // tail conv handled by the caller
         Tensor o = pl.alloc(B, hout, hout, l.out);
@@ -836,6 +849,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
                 c.launch_conv(p, tile);
             }, 2.0 * B * hout * hout * 9.0 * l.mid * l.out, 4.0 * B * hout * hout * ((double)l.mid + l.out));
             pl.ops.back().bf16x3_only = mid.split;
+            pl.ops.back().wino_ok = pc->wino != nullptr && !mid.split && h->wino;
         }
         return o;
     };
@@ -1017,6 +1031,7 @@ int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
     if (const char* e = getenv("CCVPE_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_GRAPH")) h->graph_mode = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_FUSE_L1")) h->fuse_level1 = std::atoi(e) != 0;
+    if (const char* e = getenv("CCVPE_WINOGRAD")) h->wino = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_FUSE_MBCONV")) h->fuse_mbconv = std::atoi(e);
     if (const char* e = getenv("CCVPE_PRECISION")) h->cfg.reserved[0] = (std::string(e) == "bf16x3") ? 1 : 0;
     if (h->cfg.reserved[0] != 0 && h->cfg.reserved[0] != 1) { delete h; return fail(CCVPE_EINVAL, "unknown precision mode %d", cfg->reserved[0]); }
@@ -1145,6 +1160,7 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
             if (conv_igemm_tile_util(q, t) < 0.45) continue;
             if (conv_igemm_tile_is_bf16x3(t) && h->cfg.reserved[0] != 1) continue;
             if (op.bf16x3_only && !conv_igemm_tile_is_bf16x3(t)) continue;
+            if (conv_igemm_tile_is_wino(t) && !op.wino_ok) continue;
             const long long blocks = conv_igemm_tile_blocks(q, t);
             for (int split = 1; split <= 16; split *= 2) {
                 if (split > 1) {   // split-K only where the grid underfills the chip and K is deep enough
@@ -1461,6 +1477,7 @@ int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Ci
     ConvParams p = conv_params(pc, in, Cin, B, H, W, OH, OW, stride, pad, pad, act);
     p.dst[0] = {out, Cout, 0}; p.ndst = 1;
     hipStream_t st = (hipStream_t)stream;
+    if (conv_igemm_tile_is_wino(tile) && !conv_wino_supported(p)) { cleanup(); return fail(CCVPE_EINVAL, "layer is not Winograd-shaped (3x3, stride 1, pad 1, W %% 16 == 0, H %% 8 == 0)"); }
     if (launch_conv_igemm(p, tile, st) != 0) { cleanup(); return fail(CCVPE_EINVAL, "unsupported conv geometry (KH*KW <= 16, Cin %% 8 == 0)"); }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && iters > 0 && ms) {

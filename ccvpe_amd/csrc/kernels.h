@@ -1,5 +1,7 @@
 // Internal kernel interface of libccvpe_hip.so (gfx950 only).  All activations are fp32 NHWC.
 #pragma once
+#include <functional>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -65,6 +67,10 @@ struct ConvParams {
     int splitk;                // filled by launch_conv_igemm from the cfg word: K split over gridDim.z
     float* partial;            // split-K slab scratch [splitk][M][N] (null = split-K unavailable)
     size_t partial_floats;
+    // Winograd F(2x2,3x3) form of a 3x3 / stride 1 / pad 1 layer (kernels_wino.hip); null = not packed
+    const float* wino_w;       // [Cin/8][16][wino_n16][128]
+    int wino_n16;              // ceil(N / 16)
+    unsigned wino_bytes;
 };
 
 // tile = 0 picks automatically from (M, N); otherwise one of the TILE_* ids.
@@ -81,6 +87,12 @@ void launch_splitk_reduce(const ConvParams& p, hipStream_t s);
 struct Bf16x3Tile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); };
 int bf16x3_num_tiles();
 const Bf16x3Tile* bf16x3_tile(int i);
+struct WinoTile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); };
+int wino_num_tiles();
+const WinoTile* wino_tile(int i);
+bool conv_wino_supported(const ConvParams& p);
+bool conv_igemm_tile_is_wino(int tile);
+size_t conv_wino_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out, int* n16_out);
 int conv_igemm_last_tile();  // tile id of the most recent launch on this thread (then reset to 0)
 const char* conv_igemm_tile_name(int tile);
 

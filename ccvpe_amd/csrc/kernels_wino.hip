@@ -1,0 +1,300 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores of gfx950, fully fused (no transformed tensors
+// in HBM).
+//
+// Serves the decoder double_conv 3x3 / stride 1 / pad 1 call sites of the reference (models.py:42-47 used by
+// conv6..conv2 and conv6_ori..conv2_ori, models.py:407-446): 72 % of the forward pass FLOPs.  The minimal
+// filtering form  Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A  needs 16 multiplies per 2x2 output tile and
+// channel pair instead of 36, i.e. 2.25x fewer matrix-core cycles than the implicit GEMM for the same
+// result (fp32 throughout; the transforms only add/subtract activations and the weights are transformed
+// once on the host in double precision).
+//
+// Work decomposition: a workgroup of NW wave64 owns 32 output tiles (an 8 x 4 patch of 2x2 tiles = 16 x 8
+// output pixels of one image) x 16*NW output channels, for all 16 Winograd positions xi.  K is walked in
+// chunks of 8 input channels:
+//   * each thread gathers the 4x4 input patch of one (tile, channel) with bounds-checked buffer loads (the
+//     pad-1 halo returns zeros), applies B^T d B in registers (32 adds) and scatters the 16 values to LDS;
+//   * the transformed weights of the chunk (host layout == LDS layout, 512 B per (xi, 16 channels)) are copied
+//     with 16-byte loads;
+//   * wave w then runs, for each xi, four v_mfma_f32_16x16x4_f32: 2 tile halves x 2 k-steps, from three
+//     conflict-free ds_read_b64 (a lane's two k-steps are adjacent in LDS).  The wave keeps all
+//     16 xi x 32 tiles x 16 channels accumulators (128 registers), so the inverse transform A^T M A is a
+//     per-lane affair in the epilogue.
+// Global loads of chunk i+1 are in flight under the MFMAs of chunk i (register staging, single LDS image,
+// two barriers per chunk; two workgroups per CU cover each other's barriers).
+#include "igemm_common.h"
+
+namespace ccvpe {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int NW, int GC>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino_kernel(const ConvParams p) {
+    constexpr int NT = NW * 64;
+    constexpr int ITEMS = (256 + NT - 1) / NT;             // (tile, channel) transform items per thread
+    constexpr int PXS = GC * 8 + 4;                        // floats per raw pixel in LDS (16 B pad: conflict-free reads)
+    constexpr int RAW_F4 = 180 * GC * 2;                   // float4s of one raw group (18 x 10 pixels x GC*8 channels)
+    constexpr int RAW_ITEMS = (RAW_F4 + NT - 1) / NT;
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Vs = smem;                      // [16 xi][2 halves][4 kq][16 tiles (swizzled)][2 kh]
+    float* Rs = smem + 4096;               // [10 rows][18 cols][PXS]  raw input patch of the current channel group
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    const int mbx = p.W >> 4, mby = p.H >> 3;
+    const int mblocks = p.B * mbx * mby;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nb = bid / mblocks;            // channel block slowest: neighbours in an XCD share the weight panel
+    const int mb = bid - nb * mblocks;
+    const int b = mb / (mbx * mby);
+    const int rem = mb - b * (mbx * mby);
+    const int by = rem / mbx, bx = rem - by * mbx;
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wino_w), 0, p.wino_bytes, 0x00020000);
+
+    // ---- raw patch: float4 j = tid + i*NT  ->  pixel j / (2*GC) of the 18 x 10 region, channels 4*(j % (2*GC)) ----
+    int r_off[RAW_ITEMS];     // byte offset at channel 0 (or -1: outside the image / past the item count)
+    int r_c4[RAW_ITEMS];      // first channel of the float4 inside the group
+#pragma unroll
+    for (int i = 0; i < RAW_ITEMS; ++i) {
+        const int j = tid + i * NT;
+        const int px = j / (2 * GC), q = j - px * (2 * GC);
+        const int py = px / 18, pxx = px - py * 18;
+        const int y = by * 8 - 1 + py, x = bx * 16 - 1 + pxx;
+        const bool ok = j < RAW_F4 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        r_off[i] = ok ? (((b * p.H + y) * p.W + x) * p.in_ld + q * 4) * 4 : -1;
+        r_c4[i] = q * 4;
+    }
+    // ---- transform items: (tile t, channel k of the chunk) ----
+    int g_raw[ITEMS], g_lds[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int it = tid + i * NT;
+        const int k = it & 7, t = (it >> 3) & 31;
+        g_raw[i] = ((t >> 3) * 2 * 18 + (t & 7) * 2) * PXS + k;
+        // tile slot XOR 8 for kq >= 2: the 8 tiles x 8 channels a wave scatters then cover all 64 banks once
+        g_lds[i] = (t >> 4) * 128 + ((k & 3) * 16 + ((t & 15) ^ ((k & 2) << 2))) * 2 + (k >> 2);
+    }
+    // weights never touch LDS: the host layout is the B-fragment layout, so a wave reads the 512 bytes of its
+    // (xi, 16-channel slice) with one 8-byte load per lane, straight into the MFMA operand registers
+    const bool w_ok = nb * NW + wave < p.wino_n16;
+    const unsigned w_xi_b = (unsigned)p.wino_n16 * 512u;             // bytes between consecutive xi
+    const unsigned w_chunk_b = w_xi_b * 16u;                          // bytes per chunk
+    const unsigned w_base = (unsigned)(nb * NW + wave) * 512u + (unsigned)lane * 8u;
+
+    // split-K over chunks
+    const int nch = p.Cin >> 3;
+    int c_begin = 0, c_end = nch;
+    if (p.splitk > 1) {
+        const int per = (nch + p.splitk - 1) / p.splitk;
+        c_begin = min((int)blockIdx.z * per, nch);
+        c_end = min(c_begin + per, nch);
+    }
+
+    f32x4 raw[RAW_ITEMS];
+    f32x2 bq[16];             // B fragments of the current chunk, refilled in place for the next one
+#define CCVPE_WINO_LOAD_RAW(c0)   /* channel group starting at channel c0 */                             \
+    _Pragma("unroll") for (int i = 0; i < RAW_ITEMS; ++i) {                                              \
+        const bool ok = (r_off[i] >= 0) & ((c0) + r_c4[i] < p.Cin);                                      \
+        raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? (unsigned)(r_off[i] + (c0) * 4) : OOB, 0, 0)); \
+    }
+#define CCVPE_WINO_STORE_RAW()                                                                           \
+    _Pragma("unroll") for (int i = 0; i < RAW_ITEMS; ++i) {                                              \
+        const int j = tid + i * NT;                                                                      \
+        if (RAW_ITEMS * NT == RAW_F4 || j < RAW_F4)                                                      \
+            *reinterpret_cast<f32x4*>(Rs + (j / (2 * GC)) * PXS + (j % (2 * GC)) * 4) = raw[i];          \
+    }
+#define CCVPE_WINO_LOAD_B(ch, x)                                                                         \
+    bq[x] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, w_ok ? w_base + (unsigned)(ch) * w_chunk_b + (unsigned)(x) * w_xi_b : OOB, 0, 0));
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+        acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    if (c_begin < c_end) {
+        CCVPE_WINO_LOAD_RAW(c_begin * 8);
+#pragma unroll
+        for (int x = 0; x < 16; ++x) { CCVPE_WINO_LOAD_B(c_begin, x); }
+        CCVPE_WINO_STORE_RAW();
+        __syncthreads();
+        const float* va = Vs + ((lane & 48) + ((lane & 15) ^ ((lane & 32) >> 2))) * 2;   // same slot swizzle as g_lds
+        for (int ch = c_begin; ch < c_end; ++ch) {
+            const int sub = (ch - c_begin) % GC;       // chunk inside the channel group held in Rs
+            // gather the 4x4 patch of (tile, channel) from the raw image and apply B^T d B in registers
+            float v[ITEMS][16];
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                float d[16], w[16];
+                const float* rp = Rs + g_raw[i] + sub * 8;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) d[r * 4 + c] = rp[(r * 18 + c) * PXS];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    w[0 * 4 + c] = d[0 * 4 + c] - d[2 * 4 + c];
+                    w[1 * 4 + c] = d[1 * 4 + c] + d[2 * 4 + c];
+                    w[2 * 4 + c] = d[2 * 4 + c] - d[1 * 4 + c];
+                    w[3 * 4 + c] = d[1 * 4 + c] - d[3 * 4 + c];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[i][r * 4 + 0] = w[r * 4 + 0] - w[r * 4 + 2];
+                    v[i][r * 4 + 1] = w[r * 4 + 1] + w[r * 4 + 2];
+                    v[i][r * 4 + 2] = w[r * 4 + 2] - w[r * 4 + 1];
+                    v[i][r * 4 + 3] = w[r * 4 + 1] - w[r * 4 + 3];
+                }
+            }
+            __syncthreads();   // every wave is done with the previous chunk's V/U image and with this chunk's Rs reads
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i)
+                if (NT * ITEMS == 256 || tid + i * NT < 256) {
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) Vs[x * 256 + g_lds[i]] = v[i][x];
+                }
+            const bool last_of_group = sub == GC - 1;
+            if (last_of_group) { CCVPE_WINO_STORE_RAW(); }   // next group's patch (loaded GC chunks ago)
+            __syncthreads();
+            // prefetch the next channel group when this one has just begun
+            const int chn = min(ch + 1, c_end - 1);   // the last iteration re-reads its own weights: branch-free
+            if (sub == 0) { CCVPE_WINO_LOAD_RAW((ch + GC) * 8); }
+            __builtin_amdgcn_sched_barrier(0);
+            // A fragments double-buffered in registers, two xi per step: the ds_reads of pair g+1 are in flight
+            // under the eight MFMAs of pair g (hipcc otherwise waits out the LDS latency before every group);
+            // a pair's B registers are refilled for the next chunk as soon as its MFMAs have issued, so the
+            // weight loads have a whole chunk period to land
+            f32x2 fa[2][2][2];
+#define CCVPE_WINO_FRAGS(buf, g)                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                      \
+        fa[buf][e][0] = *reinterpret_cast<const f32x2*>(va + ((g) * 2 + e) * 256);                       \
+        fa[buf][e][1] = *reinterpret_cast<const f32x2*>(va + ((g) * 2 + e) * 256 + 128);                 \
+    }
+            CCVPE_WINO_FRAGS(0, 0);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int cur = g & 1;
+                if (g + 1 < 8) { CCVPE_WINO_FRAGS(cur ^ 1, g + 1); }
+                __builtin_amdgcn_sched_barrier(0);   // pin the reads above this pair's MFMAs
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int x = g * 2 + e;
+                    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][e][0].x, bq[x].x, acc[x][0], 0, 0, 0);
+                    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][e][1].x, bq[x].x, acc[x][1], 0, 0, 0);
+                    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][e][0].y, bq[x].y, acc[x][0], 0, 0, 0);
+                    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][e][1].y, bq[x].y, acc[x][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                CCVPE_WINO_LOAD_B(chn, g * 2);
+                CCVPE_WINO_LOAD_B(chn, g * 2 + 1);
+            }
+#undef CCVPE_WINO_FRAGS
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef CCVPE_WINO_LOAD_RAW
+#undef CCVPE_WINO_STORE_RAW
+#undef CCVPE_WINO_LOAD_B
+
+    // ---- inverse transform A^T M A, bias, activation, store ----
+    const int n = (nb * NW + wave) * 16 + (lane & 15);
+    if (n >= p.N) return;
+    const float bias = p.splitk > 1 ? 0.f : p.bias[n];
+    const Dst dst = p.dst[0];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = h * 16 + (lane >> 4) * 4 + i;
+            float tt[2][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float m0 = acc[0 * 4 + c][h][i], m1 = acc[1 * 4 + c][h][i], m2 = acc[2 * 4 + c][h][i], m3 = acc[3 * 4 + c][h][i];
+                tt[0][c] = m0 + m1 + m2;
+                tt[1][c] = m1 - m2 - m3;
+            }
+            const int oy = (by * 4 + (t >> 3)) * 2, ox = (bx * 8 + (t & 7)) * 2;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float y0 = tt[a][0] + tt[a][1] + tt[a][2];
+                const float y1 = tt[a][1] - tt[a][2] - tt[a][3];
+                const size_t m = ((size_t)b * p.H + oy + a) * p.W + ox;
+                if (p.splitk > 1) {
+                    float* o = p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n;
+                    o[0] = y0;
+                    o[p.N] = y1;
+                } else {
+                    float* o = dst.ptr + m * dst.ld + dst.coff + n;
+                    o[0] = apply_act(y0 + bias, p.act);
+                    o[dst.ld] = apply_act(y1 + bias, p.act);
+                }
+            }
+        }
+}
+
+template <int NW, int GC>
+static void launch_wino(const ConvParams& p, hipStream_t s) {
+    constexpr size_t lds = (4096 + 180 * (GC * 8 + 4)) * sizeof(float);
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    static bool attr_done = false;
+    auto kern = conv_wino_kernel<NW, GC>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int mblocks = p.B * (p.W >> 4) * (p.H >> 3);
+    const int nblocks = (p.wino_n16 + NW - 1) / NW;
+    dim3 grid(mblocks * nblocks, 1, p.splitk > 1 ? p.splitk : 1);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+    if (p.splitk > 1) launch_splitk_reduce(p, s);
+}
+
+static const WinoTile WINO_TILES[] = {
+    {128, 32, "conv_wino_32x32", launch_wino<2, 4>},
+    {128, 48, "conv_wino_32x48", launch_wino<3, 4>},
+    {128, 64, "conv_wino_32x64", launch_wino<4, 4>},
+    {128, 80, "conv_wino_32x80", launch_wino<5, 4>},
+};
+int wino_num_tiles() { return (int)(sizeof(WINO_TILES) / sizeof(WINO_TILES[0])); }
+const WinoTile* wino_tile(int i) { return &WINO_TILES[i]; }
+
+bool conv_wino_supported(const ConvParams& p) {
+    return p.wino_w != nullptr && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.mode == MODE_CONV &&
+           p.gate == nullptr && p.resid == nullptr && p.ndst == 1 && !p.dst[0].split && !p.in_split && p.OH == p.H && p.OW == p.W &&
+           p.W % 16 == 0 && p.H % 8 == 0 && p.Cin % 8 == 0;
+}
+
+// Host-side weight transform: U = G g G^T per (cout, cin) in double precision, stored in the LDS image order
+//   [chunk = cin/8][xi][n16][kq = cin%4][nn = cout%16][kh = (cin%8)/4]      (512 B per (xi, n16) = one B-fragment load of a wave)
+// `get(n, tap, c)` returns the 3x3 weight (tap = ky*3 + kx).
+size_t conv_wino_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out, int* n16_out) {
+    static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    const int n16 = (N + 15) / 16;
+    const int nch = cin / 8;
+    out.assign((size_t)nch * 16 * n16 * 128, 0.f);
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < cin; ++c) {
+            double g[3][3], tmp[4][3];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) g[i][j] = (double)get(n, i * 3 + j, c);
+            for (int r = 0; r < 4; ++r)
+                for (int j = 0; j < 3; ++j) tmp[r][j] = G[r][0] * g[0][j] + G[r][1] * g[1][j] + G[r][2] * g[2][j];
+            const int chunk = c / 8, k = c % 8;
+            for (int r = 0; r < 4; ++r)
+                for (int q = 0; q < 4; ++q) {
+                    const double uv = tmp[r][0] * G[q][0] + tmp[r][1] * G[q][1] + tmp[r][2] * G[q][2];
+                    const size_t idx = ((((size_t)chunk * 16 + (r * 4 + q)) * n16 + n / 16) * 4 + (k & 3)) * 32 + (n % 16) * 2 + (k >> 2);
+                    out[idx] = (float)uv;
+                }
+        }
+    *n16_out = n16;
+    return out.size();
+}
+
+}  // namespace ccvpe

@@ -58,11 +58,46 @@ def test_every_tile_config_is_correct():
     n = lib.ccvpe_op_num_tiles()
     assert n >= 8
     for t in range(1, n + 1):
+        name = lib.ccvpe_op_tile_name(t).decode()
+        if "wino" in name:       # 19 x 23 is not Winograd-shaped: covered by test_winograd_*
+            with pytest.raises(_lib.CcvpeError):
+                _lib.op_conv2d(x, w, b, 1, 1, 0, t)
+            continue
         out, _ = _lib.op_conv2d(x, w, b, 1, 1, 0, t)
         err = (out - ref).abs().max().item() / ref.abs().max().item()
-        name = lib.ccvpe_op_tile_name(t).decode()
         tol = 1e-4 if "bf16x3" in name else 2e-5      # the 3-term bf16 split carries ~2^-16 per product
         assert err <= tol, f"tile {t} ({name}): {err:.3g}"
+
+
+WINO_SHAPES = [
+    # B, H, W, Cin, Cout
+    (1, 8, 16, 8, 16),
+    (3, 16, 16, 64, 88),
+    (2, 24, 32, 24, 40),
+    (1, 32, 48, 104, 17),
+    (2, 16, 16, 200, 160),
+    (1, 64, 64, 16, 100),
+]
+
+
+@pytest.mark.parametrize("shape", WINO_SHAPES)
+def test_winograd_tiles_match_torch(shape):
+    """Winograd F(2x2,3x3) kernels (decoder double_conv, models.py:42-47): every NW variant, ragged Cout,
+    bias + ReLU epilogue, halo handling at all four image borders."""
+    lib = _lib.load()
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    tiles = [t for t in range(1, lib.ccvpe_op_num_tiles() + 1) if b"wino" in lib.ccvpe_op_tile_name(t)]
+    assert len(tiles) >= 3
+    for act in (0, 1):
+        ref = ref_conv(x, w, b, 1, 1, act)
+        for t in tiles:
+            out, _ = _lib.op_conv2d(x, w, b, 1, 1, act, t)
+            err = (out - ref).abs().max().item() / ref.abs().max().item()
+            assert err <= 2e-5, f"tile {lib.ccvpe_op_tile_name(t).decode()} act {act}: {err:.3g}"
 
 
 def test_conv2d_rejects_bad_geometry():
