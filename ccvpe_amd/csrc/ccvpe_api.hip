@@ -1477,7 +1477,7 @@ int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Ci
     ConvParams p = conv_params(pc, in, Cin, B, H, W, OH, OW, stride, pad, pad, act);
     p.dst[0] = {out, Cout, 0}; p.ndst = 1;
     hipStream_t st = (hipStream_t)stream;
-    if (conv_igemm_tile_is_wino(tile) && !conv_wino_supported(p)) { cleanup(); return fail(CCVPE_EINVAL, "layer is not Winograd-shaped (3x3, stride 1, pad 1, W %% 16 == 0, H %% 8 == 0)"); }
+    if (conv_igemm_tile_is_wino(tile) && !conv_wino_supported(p)) { cleanup(); return fail(CCVPE_EINVAL, "layer is not Winograd-shaped (3x3, stride 1, pad 1, W %% 16 == 0, H %% 16 == 0)"); }
     if (launch_conv_igemm(p, tile, st) != 0) { cleanup(); return fail(CCVPE_EINVAL, "unsupported conv geometry (KH*KW <= 16, Cin %% 8 == 0)"); }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && iters > 0 && ms) {

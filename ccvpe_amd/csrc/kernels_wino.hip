@@ -27,24 +27,29 @@ namespace ccvpe {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NW, int GC>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino_kernel(const ConvParams p) {
-    constexpr int NT = NW * 64;
-    constexpr int ITEMS = (256 + NT - 1) / NT;             // (tile, channel) transform items per thread
+// NW channel slices (16 output channels each) x NM tile sets (8 x 4 tiles each, stacked vertically) per workgroup,
+// one wave per (slice, set); GC = 8-channel chunks per raw-patch refresh.
+template <int NW, int NM, int GC>
+__global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino_kernel(const ConvParams p) {
+    constexpr int NT = NW * NM * 64;
+    constexpr int NITEM = 256 * NM;                        // (tile, channel) transform items per chunk
+    constexpr int ITEMS = (NITEM + NT - 1) / NT;
     constexpr int PXS = GC * 8 + 4;                        // floats per raw pixel in LDS (16 B pad: conflict-free reads)
-    constexpr int RAW_F4 = 180 * GC * 2;                   // float4s of one raw group (18 x 10 pixels x GC*8 channels)
+    constexpr int PROWS = 8 * NM + 2;                      // raw patch: PROWS x 18 pixels
+    constexpr int RAW_F4 = PROWS * 18 * GC * 2;            // float4s of one raw group (GC*8 channels per pixel)
     constexpr int RAW_ITEMS = (RAW_F4 + NT - 1) / NT;
     constexpr unsigned OOB = 0x80000000u;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Vs = smem;                      // [16 xi][2 halves][4 kq][16 tiles (swizzled)][2 kh]
-    float* Rs = smem + 4096;               // [10 rows][18 cols][PXS]  raw input patch of the current channel group
+    float* Vs = smem;                      // [NM sets][16 xi][2 halves][4 kq][16 tiles (swizzled)][2 kh]
+    float* Rs = smem + 4096 * NM;          // [PROWS][18 cols][PXS]  raw input patch of the current channel group
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = (tid >> 6) % NW;      // channel slice
+    const int wset = (tid >> 6) / NW;      // tile set
 
-    const int mbx = p.W >> 4, mby = p.H >> 3;
+    const int mbx = p.W >> 4, mby = p.H / (8 * NM);
     const int mblocks = p.B * mbx * mby;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int nb = bid / mblocks;            // channel block slowest: neighbours in an XCD share the weight panel
@@ -57,34 +62,35 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wino_w), 0, p.wino_bytes, 0x00020000);
 
     // ---- raw patch: float4 j = tid + i*NT  ->  pixel j / (2*GC) of the 18 x 10 region, channels 4*(j % (2*GC)) ----
-    int r_off[RAW_ITEMS];     // byte offset at channel 0 (or -1: outside the image / past the item count)
-    int r_c4[RAW_ITEMS];      // first channel of the float4 inside the group
+    // per-thread part of the address (buffer voffset); the channel-group offset is uniform and travels in the
+    // scalar soffset operand, so the loads cost no vector ALU work inside the K loop (non-MFMA VALU
+    // instructions take matrix-pipe issue slots on gfx950)
+    unsigned r_off[RAW_ITEMS];
 #pragma unroll
     for (int i = 0; i < RAW_ITEMS; ++i) {
         const int j = tid + i * NT;
         const int px = j / (2 * GC), q = j - px * (2 * GC);
         const int py = px / 18, pxx = px - py * 18;
-        const int y = by * 8 - 1 + py, x = bx * 16 - 1 + pxx;
+        const int y = by * 8 * NM - 1 + py, x = bx * 16 - 1 + pxx;
         const bool ok = j < RAW_F4 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-        r_off[i] = ok ? (((b * p.H + y) * p.W + x) * p.in_ld + q * 4) * 4 : -1;
-        r_c4[i] = q * 4;
+        r_off[i] = ok ? (unsigned)((((b * p.H + y) * p.W + x) * p.in_ld + q * 4) * 4) : OOB;
     }
     // ---- transform items: (tile t, channel k of the chunk) ----
     int g_raw[ITEMS], g_lds[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int it = tid + i * NT;
-        const int k = it & 7, t = (it >> 3) & 31;
-        g_raw[i] = ((t >> 3) * 2 * 18 + (t & 7) * 2) * PXS + k;
+        const int k = it & 7, tg = (it >> 3) & (32 * NM - 1), t = tg & 31;   // tg: tile inside the block, t: inside its set
+        g_raw[i] = ((tg >> 3) * 2 * 18 + (tg & 7) * 2) * PXS + k;
         // tile slot XOR 8 for kq >= 2: the 8 tiles x 8 channels a wave scatters then cover all 64 banks once
-        g_lds[i] = (t >> 4) * 128 + ((k & 3) * 16 + ((t & 15) ^ ((k & 2) << 2))) * 2 + (k >> 2);
+        g_lds[i] = (tg >> 5) * 4096 + (t >> 4) * 128 + ((k & 3) * 16 + ((t & 15) ^ ((k & 2) << 2))) * 2 + (k >> 2);
     }
     // weights never touch LDS: the host layout is the B-fragment layout, so a wave reads the 512 bytes of its
     // (xi, 16-channel slice) with one 8-byte load per lane, straight into the MFMA operand registers
     const bool w_ok = nb * NW + wave < p.wino_n16;
     const unsigned w_xi_b = (unsigned)p.wino_n16 * 512u;             // bytes between consecutive xi
     const unsigned w_chunk_b = w_xi_b * 16u;                          // bytes per chunk
-    const unsigned w_base = (unsigned)(nb * NW + wave) * 512u + (unsigned)lane * 8u;
+    const unsigned w_base = w_ok ? (unsigned)(nb * NW + wave) * 512u + (unsigned)lane * 8u : OOB;
 
     // split-K over chunks
     const int nch = p.Cin >> 3;
@@ -97,11 +103,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     f32x4 raw[RAW_ITEMS];
     f32x2 bq[16];             // B fragments of the current chunk, refilled in place for the next one
+    // channels past Cin in the last (partial) group land in Rs but are never read: the chunk loop stops at Cin / 8
 #define CCVPE_WINO_LOAD_RAW(c0)   /* channel group starting at channel c0 */                             \
-    _Pragma("unroll") for (int i = 0; i < RAW_ITEMS; ++i) {                                              \
-        const bool ok = (r_off[i] >= 0) & ((c0) + r_c4[i] < p.Cin);                                      \
-        raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? (unsigned)(r_off[i] + (c0) * 4) : OOB, 0, 0)); \
-    }
+    _Pragma("unroll") for (int i = 0; i < RAW_ITEMS; ++i)                                                \
+        raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, r_off[i], (c0) * 4, 0));
 #define CCVPE_WINO_STORE_RAW()                                                                           \
     _Pragma("unroll") for (int i = 0; i < RAW_ITEMS; ++i) {                                              \
         const int j = tid + i * NT;                                                                      \
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             *reinterpret_cast<f32x4*>(Rs + (j / (2 * GC)) * PXS + (j % (2 * GC)) * 4) = raw[i];          \
     }
 #define CCVPE_WINO_LOAD_B(ch, x)                                                                         \
-    bq[x] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, w_ok ? w_base + (unsigned)(ch) * w_chunk_b + (unsigned)(x) * w_xi_b : OOB, 0, 0));
+    bq[x] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, w_base, (ch) * w_chunk_b + (x) * w_xi_b, 0));
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int x = 0; x < 16; ++x) { CCVPE_WINO_LOAD_B(c_begin, x); }
         CCVPE_WINO_STORE_RAW();
         __syncthreads();
-        const float* va = Vs + ((lane & 48) + ((lane & 15) ^ ((lane & 32) >> 2))) * 2;   // same slot swizzle as g_lds
+        const float* va = Vs + wset * 4096 + ((lane & 48) + ((lane & 15) ^ ((lane & 32) >> 2))) * 2;   // same slot swizzle as g_lds
         for (int ch = c_begin; ch < c_end; ++ch) {
             const int sub = (ch - c_begin) % GC;       // chunk inside the channel group held in Rs
             // gather the 4x4 patch of (tile, channel) from the raw image and apply B^T d B in registers
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             __syncthreads();   // every wave is done with the previous chunk's V/U image and with this chunk's Rs reads
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i)
-                if (NT * ITEMS == 256 || tid + i * NT < 256) {
+                if (NT * ITEMS == NITEM || tid + i * NT < NITEM) {
 #pragma unroll
                     for (int x = 0; x < 16; ++x) Vs[x * 256 + g_lds[i]] = v[i][x];
                 }
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 tt[0][c] = m0 + m1 + m2;
                 tt[1][c] = m1 - m2 - m3;
             }
-            const int oy = (by * 4 + (t >> 3)) * 2, ox = (bx * 8 + (t & 7)) * 2;
+            const int oy = ((by * NM + wset) * 4 + (t >> 3)) * 2, ox = (bx * 8 + (t & 7)) * 2;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const float y0 = tt[a][0] + tt[a][1] + tt[a][2];
@@ -238,28 +243,30 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
 }
 
-template <int NW, int GC>
+template <int NW, int NM, int GC>
 static void launch_wino(const ConvParams& p, hipStream_t s) {
-    constexpr size_t lds = (4096 + 180 * (GC * 8 + 4)) * sizeof(float);
+    constexpr size_t lds = (4096 * NM + (8 * NM + 2) * 18 * (GC * 8 + 4)) * sizeof(float);
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     static bool attr_done = false;
-    auto kern = conv_wino_kernel<NW, GC>;
+    auto kern = conv_wino_kernel<NW, NM, GC>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    const int mblocks = p.B * (p.W >> 4) * (p.H >> 3);
+    const int mblocks = p.B * (p.W >> 4) * (p.H / (8 * NM));
     const int nblocks = (p.wino_n16 + NW - 1) / NW;
     dim3 grid(mblocks * nblocks, 1, p.splitk > 1 ? p.splitk : 1);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * NM * 64), lds, s, p);
     if (p.splitk > 1) launch_splitk_reduce(p, s);
 }
 
+// bm = output pixels per workgroup (32 tiles x 4 pixels per set), bn = output channels per workgroup
 static const WinoTile WINO_TILES[] = {
-    {128, 32, "conv_wino_32x32", launch_wino<2, 4>},
-    {128, 48, "conv_wino_32x48", launch_wino<3, 4>},
-    {128, 64, "conv_wino_32x64", launch_wino<4, 4>},
-    {128, 80, "conv_wino_32x80", launch_wino<5, 4>},
+    {256, 32, "conv_wino_64x32", launch_wino<2, 2, 2>},
+    {128, 48, "conv_wino_32x48", launch_wino<3, 1, 4>},
+    {128, 64, "conv_wino_32x64", launch_wino<4, 1, 4>},
+    {128, 80, "conv_wino_32x80", launch_wino<5, 1, 4>},
+    {256, 48, "conv_wino_64x48", launch_wino<3, 2, 2>},
 };
 int wino_num_tiles() { return (int)(sizeof(WINO_TILES) / sizeof(WINO_TILES[0])); }
 const WinoTile* wino_tile(int i) { return &WINO_TILES[i]; }
@@ -267,7 +274,7 @@ const WinoTile* wino_tile(int i) { return &WINO_TILES[i]; }
 bool conv_wino_supported(const ConvParams& p) {
     return p.wino_w != nullptr && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.mode == MODE_CONV &&
            p.gate == nullptr && p.resid == nullptr && p.ndst == 1 && !p.dst[0].split && !p.in_split && p.OH == p.H && p.OW == p.W &&
-           p.W % 16 == 0 && p.H % 8 == 0 && p.Cin % 8 == 0;
+           p.W % 16 == 0 && p.H % 16 == 0 && p.Cin % 8 == 0;
 }
 
 // Host-side weight transform: U = G g G^T per (cout, cin) in double precision, stored in the LDS image order

@@ -71,9 +71,9 @@ def test_every_tile_config_is_correct():
 
 WINO_SHAPES = [
     # B, H, W, Cin, Cout
-    (1, 8, 16, 8, 16),
+    (1, 16, 16, 8, 16),
     (3, 16, 16, 64, 88),
-    (2, 24, 32, 24, 40),
+    (2, 48, 32, 24, 40),
     (1, 32, 48, 104, 17),
     (2, 16, 16, 200, 160),
     (1, 64, 64, 16, 100),

@@ -9,10 +9,10 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" \
            "SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" \
            "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32" \
-           "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN2_sum" \
+           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INSTS_MFMA" \
            "FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  (cd /tmp && rocprofv3 --pmc $set --kernel-trace -d "$root/$out/p$i" -o run --output-format csv -- python3 "$root/tools/pmc_conv.py" "$@" > "$root/$out/p$i.log" 2>&1) || echo "pass $i failed"
+  (cd /tmp && timeout -k 10 120 rocprofv3 --pmc $set --kernel-trace -d "$root/$out/p$i" -o run --output-format csv -- python3 "$root/tools/pmc_conv.py" "$@" > "$root/$out/p$i.log" 2>&1) || echo "pass $i failed"
 done
 python3 - "$root/$out" <<'PY'
 import csv, glob, sys, collections
