@@ -136,25 +136,29 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
             float v[ITEMS][16];
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
-                float d[16], w[16];
-                const float* rp = Rs + g_raw[i] + sub * 8;
+                const float* rp_ = Rs + g_raw[i] + sub * 8;
+                // B^T d B on register pairs: D[r][cp] = patch pixels (r, 2cp) and (r, 2cp+1) (one ds_read2_b32 each),
+                // row pass = 8 packed adds, column pass = 8 packed adds whose operand halves are picked with
+                // op_sel / neg modifiers (hipcc would insert v_mov shuffles; every VALU slot here is a lost
+                // matrix-pipe slot)
+                f32x2 D[4][2], X[4][2];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) d[r * 4 + c] = rp[(r * 18 + c) * PXS];
+                    for (int cp = 0; cp < 2; ++cp) D[r][cp] = f32x2{rp_[(r * 18 + 2 * cp) * PXS], rp_[(r * 18 + 2 * cp + 1) * PXS]};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    w[0 * 4 + c] = d[0 * 4 + c] - d[2 * 4 + c];
-                    w[1 * 4 + c] = d[1 * 4 + c] + d[2 * 4 + c];
-                    w[2 * 4 + c] = d[2 * 4 + c] - d[1 * 4 + c];
-                    w[3 * 4 + c] = d[1 * 4 + c] - d[3 * 4 + c];
+                for (int cp = 0; cp < 2; ++cp) {
+                    X[0][cp] = D[0][cp] - D[2][cp];
+                    X[1][cp] = D[1][cp] + D[2][cp];
+                    X[2][cp] = D[2][cp] - D[1][cp];
+                    X[3][cp] = D[1][cp] - D[3][cp];
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[i][r * 4 + 0] = w[r * 4 + 0] - w[r * 4 + 2];
-                    v[i][r * 4 + 1] = w[r * 4 + 1] + w[r * 4 + 2];
-                    v[i][r * 4 + 2] = w[r * 4 + 2] - w[r * 4 + 1];
-                    v[i][r * 4 + 3] = w[r * 4 + 1] - w[r * 4 + 3];
+                    f32x2 lo, hi;   // lo = (x0 - x2, x1 + x2), hi = (x2 - x1, x1 - x3) with (x0,x1) = X[r][0], (x2,x3) = X[r][1]
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(lo) : "v"(X[r][0]), "v"(X[r][1]));
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(hi) : "v"(X[r][1]), "v"(X[r][0]));
+                    v[i][r * 4 + 0] = lo.x; v[i][r * 4 + 1] = lo.y; v[i][r * 4 + 2] = hi.x; v[i][r * 4 + 3] = hi.y;
                 }
             }
             __syncthreads();   // every wave is done with the previous chunk's V/U image and with this chunk's Rs reads
@@ -208,39 +212,42 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
 #undef CCVPE_WINO_LOAD_B
 
     // ---- inverse transform A^T M A, bias, activation, store ----
+    // Vector ALU work here also costs matrix-pipe slots, so: the transform runs on the accumulator quads (four
+    // horizontally adjacent tiles per lane -> packed fp32 adds), and the stores are buffer stores whose per-lane
+    // offset is computed once - the (tile, pixel) part of every address is uniform and rides in soffset.
     const int n = (nb * NW + wave) * 16 + (lane & 15);
-    if (n >= p.N) return;
-    const float bias = p.splitk > 1 ? 0.f : p.bias[n];
-    const Dst dst = p.dst[0];
+    const bool split = p.splitk > 1;
+    const float bias = (split || n >= p.N) ? 0.f : p.bias[n];
+    const int ld = split ? p.N : p.dst[0].ld;
+    // first output pixel of this wave's tile set
+    const size_t pix0 = ((size_t)b * p.H + (size_t)(by * NM + wset) * 8) * p.W + (size_t)bx * 16;
+    float* obase = split ? p.partial + ((size_t)blockIdx.z * p.M + pix0) * p.N : p.dst[0].ptr + pix0 * ld + p.dst[0].coff;
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0x7fffffff, 0x00020000);
+    // lane part: tile row 2*h + (lane >> 5) of the set, tile column 4 * ((lane >> 4) & 1) + i, channel n
+    const unsigned o_lane = n < p.N ? (unsigned)((((lane >> 5) * 2 * p.W + ((lane >> 4) & 1) * 8) * ld + n) * 4) : OOB;
+    const int act = split ? ACT_NONE : p.act;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h) {
+        f32x4 tt[2][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int t = h * 16 + (lane >> 4) * 4 + i;
-            float tt[2][4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float m0 = acc[0 * 4 + c][h][i], m1 = acc[1 * 4 + c][h][i], m2 = acc[2 * 4 + c][h][i], m3 = acc[3 * 4 + c][h][i];
-                tt[0][c] = m0 + m1 + m2;
-                tt[1][c] = m1 - m2 - m3;
-            }
-            const int oy = ((by * NM + wset) * 4 + (t >> 3)) * 2, ox = (bx * 8 + (t & 7)) * 2;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const float y0 = tt[a][0] + tt[a][1] + tt[a][2];
-                const float y1 = tt[a][1] - tt[a][2] - tt[a][3];
-                const size_t m = ((size_t)b * p.H + oy + a) * p.W + ox;
-                if (p.splitk > 1) {
-                    float* o = p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n;
-                    o[0] = y0;
-                    o[p.N] = y1;
-                } else {
-                    float* o = dst.ptr + m * dst.ld + dst.coff + n;
-                    o[0] = apply_act(y0 + bias, p.act);
-                    o[dst.ld] = apply_act(y1 + bias, p.act);
-                }
-            }
+        for (int c = 0; c < 4; ++c) {
+            tt[0][c] = acc[0 * 4 + c][h] + acc[1 * 4 + c][h] + acc[2 * 4 + c][h];
+            tt[1][c] = acc[1 * 4 + c][h] - acc[2 * 4 + c][h] - acc[3 * 4 + c][h];
         }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            f32x4 y[2];
+            y[0] = tt[a][0] + tt[a][1] + tt[a][2] + bias;
+            y[1] = tt[a][1] - tt[a][2] - tt[a][3] + bias;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int soff = (((h * 4 + a) * p.W + i * 2 + dx) * ld) * 4;   // uniform
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(y[dx][i], act)), o_rsrc, o_lane, soff, 0);
+                }
+        }
+    }
 }
 
 template <int NW, int NM, int GC>
