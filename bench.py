@@ -191,7 +191,7 @@ def main():
             gr = groups.setdefault(tag, [0.0, 0.0, 0.0, 0])
             gr[0] += ms; gr[1] += fl; gr[2] += by; gr[3] += 1
         total_ms = sum(v[0] for v in groups.values())
-        mfma = {k: v for k, v in groups.items() if k.startswith("conv_igemm") or k.startswith("conv_bf16x3")}
+        mfma = {k: v for k, v in groups.items() if k.startswith(("conv_igemm", "conv_bf16x3", "conv_wino"))}
         dom = max(mfma, key=lambda k: mfma[k][0])
         ms, fl, by, cnt = mfma[dom]
         all_ms = sum(v[0] for v in mfma.values())
@@ -206,6 +206,13 @@ def main():
                                  "share_of_step": all_ms / total_ms},
             "hbm_kernels_share_of_step": 1.0 - all_ms / total_ms,
         }
+        if dom.startswith("conv_wino"):
+            # `achieved` counts the layer's direct-convolution FLOPs (the algorithmic work); the Winograd
+            # F(2x2,3x3) form issues 16/36 of them on the matrix pipe, so frac can exceed 1 - the pipe's own
+            # utilisation is reported next to it
+            ex = fl / 2.25 / (ms * 1e-3) / 1e12
+            line["roofline"]["matrix_pipe"] = {"executed": ex, "frac": ex / PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                               "note": "Winograd F(2x2,3x3): executed = algorithmic / 2.25 (channel padding not counted)"}
         if args.breakdown:
             print(f"{'launch':40s} {'ms':>9s} {'TFLOP/s':>9s} {'GB/s':>9s}", file=sys.stderr)
             for name, ms_, fl_, by_ in rows:

@@ -23,6 +23,8 @@
 // two barriers per chunk; two workgroups per CU cover each other's barriers).
 #include "igemm_common.h"
 
+#include <algorithm>
+
 namespace ccvpe {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -39,10 +41,14 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
     constexpr int RAW_F4 = PROWS * 18 * GC * 2;            // float4s of one raw group (GC*8 channels per pixel)
     constexpr int RAW_ITEMS = (RAW_F4 + NT - 1) / NT;
     constexpr unsigned OOB = 0x80000000u;
+    // V image double-buffered when it fits twice beside a second workgroup (single tile set): the transform of chunk
+    // i+1 is then written while slower waves still read chunk i - one barrier per chunk instead of two
+    constexpr bool VDB = NM == 1;
+    constexpr int VSZ = 4096 * NM;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Vs = smem;                      // [NM sets][16 xi][2 halves][4 kq][16 tiles (swizzled)][2 kh]
-    float* Rs = smem + 4096 * NM;          // [PROWS][18 cols][PXS]  raw input patch of the current channel group
+    float* Vs = smem;                          // [VDB ? 2 : 1][NM sets][16 xi][2 halves][4 kq][16 tiles (swizzled)][2 kh]
+    float* Rs = smem + VSZ * (VDB ? 2 : 1);    // [PROWS][18 cols][PXS]  raw input patch of the current channel group
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -51,30 +57,49 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
 
     const int mbx = p.W >> 4, mby = p.H / (8 * NM);
     const int mblocks = p.B * mbx * mby;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int nb = bid / mblocks;            // channel block slowest: neighbours in an XCD share the weight panel
-    const int mb = bid - nb * mblocks;
-    const int b = mb / (mbx * mby);
-    const int rem = mb - b * (mbx * mby);
-    const int by = rem / mbx, bx = rem - by * mbx;
+    const int total = mblocks * ((p.wino_n16 + NW - 1) / NW);
+
+    // ---- persistent work loop: XCD x (blockIdx.x % 8) owns a contiguous run of tiles, its workgroups stride
+    // through it.  Tile index = channel block * mblocks + m block (channel block slowest: workgroups that run
+    // together share the weight panel in their L2).  While a tile's last chunks are on the matrix pipe the next
+    // tile's first patch and weights are already in flight, and its stores drain under the next tile's MFMAs.
+    const int xcd = blockIdx.x & 7;
+    const int stride = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+    const int item_begin = xcd * (total >> 3) + min(xcd, total & 7);
+    const int item_end = item_begin + (total >> 3) + (xcd < (total & 7) ? 1 : 0);
+    int item = item_begin + ((int)blockIdx.x >> 3);
+    if (item >= item_end) return;
 
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wino_w), 0, p.wino_bytes, 0x00020000);
 
-    // ---- raw patch: float4 j = tid + i*NT  ->  pixel j / (2*GC) of the 18 x 10 region, channels 4*(j % (2*GC)) ----
-    // per-thread part of the address (buffer voffset); the channel-group offset is uniform and travels in the
-    // scalar soffset operand, so the loads cost no vector ALU work inside the K loop (non-MFMA VALU
+    int nb, b, by, bx;        // current tile (uniform)
+#define CCVPE_WINO_DECODE(it_, nb_, b_, by_, bx_)                                                        \
+    {                                                                                                    \
+        nb_ = (it_) / mblocks;                                                                           \
+        const int mb_ = (it_) - nb_ * mblocks;                                                           \
+        b_ = mb_ / (mbx * mby);                                                                          \
+        const int rem_ = mb_ - b_ * (mbx * mby);                                                         \
+        by_ = rem_ / mbx;                                                                                \
+        bx_ = rem_ - by_ * mbx;                                                                          \
+    }
+    CCVPE_WINO_DECODE(item, nb, b, by, bx);
+
+    // ---- raw patch: float4 j = tid + i*NT  ->  pixel j / (2*GC) of the PROWS x 18 region, channels 4*(j % (2*GC)).
+    // r_off is the per-thread part of the address (buffer voffset); the channel-group offset is uniform and travels
+    // in the scalar soffset operand, so the loads cost no vector ALU work inside the K loop (non-MFMA VALU
     // instructions take matrix-pipe issue slots on gfx950)
     unsigned r_off[RAW_ITEMS];
-#pragma unroll
-    for (int i = 0; i < RAW_ITEMS; ++i) {
-        const int j = tid + i * NT;
-        const int px = j / (2 * GC), q = j - px * (2 * GC);
-        const int py = px / 18, pxx = px - py * 18;
-        const int y = by * 8 * NM - 1 + py, x = bx * 16 - 1 + pxx;
-        const bool ok = j < RAW_F4 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-        r_off[i] = ok ? (unsigned)((((b * p.H + y) * p.W + x) * p.in_ld + q * 4) * 4) : OOB;
+#define CCVPE_WINO_ROFF(b_, by_, bx_, live_)                                                             \
+    _Pragma("unroll") for (int i = 0; i < RAW_ITEMS; ++i) {                                              \
+        const int j = tid + i * NT;                                                                      \
+        const int px = j / (2 * GC), q = j - px * (2 * GC);                                              \
+        const int py = px / 18, pxx = px - py * 18;                                                      \
+        const int y = (by_) * 8 * NM - 1 + py, x = (bx_) * 16 - 1 + pxx;                                 \
+        const bool ok = (live_) && j < RAW_F4 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W; \
+        r_off[i] = ok ? (unsigned)(((((b_) * p.H + y) * p.W + x) * p.in_ld + q * 4) * 4) : OOB;          \
     }
+    CCVPE_WINO_ROFF(b, by, bx, true);
     // ---- transform items: (tile t, channel k of the chunk) ----
     int g_raw[ITEMS], g_lds[ITEMS];
 #pragma unroll
@@ -87,12 +112,12 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
     }
     // weights never touch LDS: the host layout is the B-fragment layout, so a wave reads the 512 bytes of its
     // (xi, 16-channel slice) with one 8-byte load per lane, straight into the MFMA operand registers
-    const bool w_ok = nb * NW + wave < p.wino_n16;
     const unsigned w_xi_b = (unsigned)p.wino_n16 * 512u;             // bytes between consecutive xi
     const unsigned w_chunk_b = w_xi_b * 16u;                          // bytes per chunk
-    const unsigned w_base = w_ok ? (unsigned)(nb * NW + wave) * 512u + (unsigned)lane * 8u : OOB;
+#define CCVPE_WINO_WBASE(nb_) ((nb_) * NW + wave < p.wino_n16 ? (unsigned)((nb_) * NW + wave) * 512u + (unsigned)lane * 8u : OOB)
+    unsigned w_base = CCVPE_WINO_WBASE(nb);
 
-    // split-K over chunks
+    // split-K over chunks (blockIdx.z); channel groups of near-equal length, at most GC chunks each
     const int nch = p.Cin >> 3;
     int c_begin = 0, c_end = nch;
     if (p.splitk > 1) {
@@ -100,10 +125,13 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
         c_begin = min((int)blockIdx.z * per, nch);
         c_end = min(c_begin + per, nch);
     }
+    const int ngroups = (c_end - c_begin + GC - 1) / GC;
+    const int glen_lo = ngroups > 0 ? (c_end - c_begin) / ngroups : 0;       // groups [n_hi, ngroups) have this length
+    const int n_hi = ngroups > 0 ? (c_end - c_begin) - glen_lo * ngroups : 0;   // the first n_hi groups are one longer
 
     f32x4 raw[RAW_ITEMS];
     f32x2 bq[16];             // B fragments of the current chunk, refilled in place for the next one
-    // channels past Cin in the last (partial) group land in Rs but are never read: the chunk loop stops at Cin / 8
+    // channels past the group / past Cin land in Rs but are never read: the chunk loop stops at Cin / 8
 #define CCVPE_WINO_LOAD_RAW(c0)   /* channel group starting at channel c0 */                             \
     _Pragma("unroll") for (int i = 0; i < RAW_ITEMS; ++i)                                                \
         raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, r_off[i], (c0) * 4, 0));
@@ -113,8 +141,8 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
         if (RAW_ITEMS * NT == RAW_F4 || j < RAW_F4)                                                      \
             *reinterpret_cast<f32x4*>(Rs + (j / (2 * GC)) * PXS + (j % (2 * GC)) * 4) = raw[i];          \
     }
-#define CCVPE_WINO_LOAD_B(ch, x)                                                                         \
-    bq[x] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, w_base, (ch) * w_chunk_b + (x) * w_xi_b, 0));
+#define CCVPE_WINO_LOAD_B(wb, ch, x)                                                                     \
+    bq[x] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, wb, (ch) * w_chunk_b + (x) * w_xi_b, 0));
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -122,18 +150,43 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
         acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (c_begin >= c_end) return;   // empty split-K slice (the host never launches one)
 
-    if (c_begin < c_end) {
-        CCVPE_WINO_LOAD_RAW(c_begin * 8);
+    CCVPE_WINO_LOAD_RAW(c_begin * 8);
 #pragma unroll
-        for (int x = 0; x < 16; ++x) { CCVPE_WINO_LOAD_B(c_begin, x); }
-        CCVPE_WINO_STORE_RAW();
-        __syncthreads();
-        const float* va = Vs + wset * 4096 + ((lane & 48) + ((lane & 15) ^ ((lane & 32) >> 2))) * 2;   // same slot swizzle as g_lds
+    for (int x = 0; x < 16; ++x) { CCVPE_WINO_LOAD_B(w_base, c_begin, x); }
+    CCVPE_WINO_STORE_RAW();
+    __syncthreads();
+    const float* va0 = Vs + wset * 4096 + ((lane & 48) + ((lane & 15) ^ ((lane & 32) >> 2))) * 2;   // same slot swizzle as g_lds
+    int vbuf = 0;
+    const bool split = p.splitk > 1;
+    const int ld = split ? p.N : p.dst[0].ld;
+    const int act = split ? ACT_NONE : p.act;
+
+    while (true) {
+        const int item_n = item + stride;
+        const bool have_n = item_n < item_end;
+        int nb_n, b_n, by_n, bx_n;
+        CCVPE_WINO_DECODE(have_n ? item_n : item, nb_n, b_n, by_n, bx_n);
+        const unsigned w_base_n = have_n ? CCVPE_WINO_WBASE(nb_n) : OOB;
+
+        int gidx = 0, gstart = c_begin, glen = glen_lo + (n_hi > 0 ? 1 : 0);   // current channel group
         for (int ch = c_begin; ch < c_end; ++ch) {
-            const int sub = (ch - c_begin) % GC;       // chunk inside the channel group held in Rs
+            const int sub = ch - gstart;               // chunk inside the channel group held in Rs
+            const bool last_chunk = ch == c_end - 1;
+            if (sub == 0) {
+                // a group has just begun: fetch the one after it - of this tile, or the first one of the next tile
+                if (gidx == ngroups - 1) {
+                    CCVPE_WINO_ROFF(b_n, by_n, bx_n, have_n);
+                    CCVPE_WINO_LOAD_RAW(c_begin * 8);
+                } else {
+                    CCVPE_WINO_LOAD_RAW((gstart + glen) * 8);
+                }
+            }
             // gather the 4x4 patch of (tile, channel) from the raw image and apply B^T d B in registers
-            float v[ITEMS][16];
+            float* Vw = Vs + (VDB ? vbuf * VSZ : 0);
+            const float* va = va0 + (VDB ? vbuf * VSZ : 0);
+            float v[VDB ? 1 : ITEMS][16];
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const float* rp_ = Rs + g_raw[i] + sub * 8;
@@ -153,27 +206,41 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
                     X[2][cp] = D[2][cp] - D[1][cp];
                     X[3][cp] = D[1][cp] - D[3][cp];
                 }
+                float* vi = v[VDB ? 0 : i];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     f32x2 lo, hi;   // lo = (x0 - x2, x1 + x2), hi = (x2 - x1, x1 - x3) with (x0,x1) = X[r][0], (x2,x3) = X[r][1]
                     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(lo) : "v"(X[r][0]), "v"(X[r][1]));
                     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(hi) : "v"(X[r][1]), "v"(X[r][0]));
-                    v[i][r * 4 + 0] = lo.x; v[i][r * 4 + 1] = lo.y; v[i][r * 4 + 2] = hi.x; v[i][r * 4 + 3] = hi.y;
+                    vi[r * 4 + 0] = lo.x; vi[r * 4 + 1] = lo.y; vi[r * 4 + 2] = hi.x; vi[r * 4 + 3] = hi.y;
+                }
+                if (VDB && (NT * ITEMS == NITEM || tid + i * NT < NITEM)) {
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) Vw[x * 256 + g_lds[i]] = vi[x];
                 }
             }
-            __syncthreads();   // every wave is done with the previous chunk's V/U image and with this chunk's Rs reads
+            __syncthreads();   // VDB: this chunk's V image is complete; else: the previous chunk's image is free
+            if (!VDB) {
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i)
-                if (NT * ITEMS == NITEM || tid + i * NT < NITEM) {
+                for (int i = 0; i < ITEMS; ++i)
+                    if (NT * ITEMS == NITEM || tid + i * NT < NITEM) {
 #pragma unroll
-                    for (int x = 0; x < 16; ++x) Vs[x * 256 + g_lds[i]] = v[i][x];
-                }
-            const bool last_of_group = sub == GC - 1;
-            if (last_of_group) { CCVPE_WINO_STORE_RAW(); }   // next group's patch (loaded GC chunks ago)
-            __syncthreads();
-            // prefetch the next channel group when this one has just begun
-            const int chn = min(ch + 1, c_end - 1);   // the last iteration re-reads its own weights: branch-free
-            if (sub == 0) { CCVPE_WINO_LOAD_RAW((ch + GC) * 8); }
+                        for (int x = 0; x < 16; ++x) Vw[x * 256 + g_lds[i]] = v[VDB ? 0 : i][x];
+                    }
+            }
+            // every wave has also finished this chunk's Rs reads by now
+            const bool group_end = sub == glen - 1;
+            if (group_end) {   // bring in the next group's patch (loaded glen chunks ago)
+                CCVPE_WINO_STORE_RAW();
+                gstart += glen;
+                ++gidx;
+                glen = glen_lo + (gidx < n_hi ? 1 : 0);
+            }
+            if (!VDB || group_end) __syncthreads();
+            vbuf ^= 1;
+            // the next chunk's weights: of this tile, or chunk c_begin of the next tile's channel block
+            const unsigned wb = last_chunk ? w_base_n : w_base;
+            const int chn = last_chunk ? c_begin : ch + 1;
             __builtin_amdgcn_sched_barrier(0);
             // A fragments double-buffered in registers, two xi per step: the ds_reads of pair g+1 are in flight
             // under the eight MFMAs of pair g (hipcc otherwise waits out the LDS latency before every group);
@@ -200,59 +267,68 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
                     acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][e][1].y, bq[x].y, acc[x][1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                CCVPE_WINO_LOAD_B(chn, g * 2);
-                CCVPE_WINO_LOAD_B(chn, g * 2 + 1);
+                CCVPE_WINO_LOAD_B(wb, chn, g * 2);
+                CCVPE_WINO_LOAD_B(wb, chn, g * 2 + 1);
             }
 #undef CCVPE_WINO_FRAGS
             __builtin_amdgcn_sched_barrier(0);
         }
+
+        // ---- inverse transform A^T M A, bias, activation, store ----
+        // Vector ALU work here also costs matrix-pipe slots, so: the transform runs on the accumulator quads (four
+        // horizontally adjacent tiles per lane -> packed fp32 adds), and the stores are buffer stores whose per-lane
+        // offset is computed once per tile - the (tile, pixel) part of every address is uniform and rides in soffset.
+        {
+            const int n = (nb * NW + wave) * 16 + (lane & 15);
+            const float bias = (split || n >= p.N) ? 0.f : p.bias[n];
+            // first output pixel of this wave's tile set
+            const size_t pix0 = ((size_t)b * p.H + (size_t)(by * NM + wset) * 8) * p.W + (size_t)bx * 16;
+            float* obase = split ? p.partial + ((size_t)blockIdx.z * p.M + pix0) * p.N : p.dst[0].ptr + pix0 * ld + p.dst[0].coff;
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0x7fffffff, 0x00020000);
+            // lane part: tile row 2*h + (lane >> 5) of the set, tile column 4 * ((lane >> 4) & 1) + i, channel n
+            const unsigned o_lane = n < p.N ? (unsigned)((((lane >> 5) * 2 * p.W + ((lane >> 4) & 1) * 8) * ld + n) * 4) : OOB;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 tt[2][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    tt[0][c] = acc[0 * 4 + c][h] + acc[1 * 4 + c][h] + acc[2 * 4 + c][h];
+                    tt[1][c] = acc[1 * 4 + c][h] - acc[2 * 4 + c][h] - acc[3 * 4 + c][h];
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    f32x4 y[2];
+                    y[0] = tt[a][0] + tt[a][1] + tt[a][2] + bias;
+                    y[1] = tt[a][1] - tt[a][2] - tt[a][3] + bias;
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int soff = (((h * 4 + a) * p.W + i * 2 + dx) * ld) * 4;   // uniform
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(y[dx][i], act)), o_rsrc, o_lane, soff, 0);
+                        }
+                }
+            }
+        }
+        if (!have_n) break;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+            acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        item = item_n; nb = nb_n; b = b_n; by = by_n; bx = bx_n; w_base = w_base_n;
     }
 #undef CCVPE_WINO_LOAD_RAW
 #undef CCVPE_WINO_STORE_RAW
 #undef CCVPE_WINO_LOAD_B
-
-    // ---- inverse transform A^T M A, bias, activation, store ----
-    // Vector ALU work here also costs matrix-pipe slots, so: the transform runs on the accumulator quads (four
-    // horizontally adjacent tiles per lane -> packed fp32 adds), and the stores are buffer stores whose per-lane
-    // offset is computed once - the (tile, pixel) part of every address is uniform and rides in soffset.
-    const int n = (nb * NW + wave) * 16 + (lane & 15);
-    const bool split = p.splitk > 1;
-    const float bias = (split || n >= p.N) ? 0.f : p.bias[n];
-    const int ld = split ? p.N : p.dst[0].ld;
-    // first output pixel of this wave's tile set
-    const size_t pix0 = ((size_t)b * p.H + (size_t)(by * NM + wset) * 8) * p.W + (size_t)bx * 16;
-    float* obase = split ? p.partial + ((size_t)blockIdx.z * p.M + pix0) * p.N : p.dst[0].ptr + pix0 * ld + p.dst[0].coff;
-    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0x7fffffff, 0x00020000);
-    // lane part: tile row 2*h + (lane >> 5) of the set, tile column 4 * ((lane >> 4) & 1) + i, channel n
-    const unsigned o_lane = n < p.N ? (unsigned)((((lane >> 5) * 2 * p.W + ((lane >> 4) & 1) * 8) * ld + n) * 4) : OOB;
-    const int act = split ? ACT_NONE : p.act;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        f32x4 tt[2][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            tt[0][c] = acc[0 * 4 + c][h] + acc[1 * 4 + c][h] + acc[2 * 4 + c][h];
-            tt[1][c] = acc[1 * 4 + c][h] - acc[2 * 4 + c][h] - acc[3 * 4 + c][h];
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            f32x4 y[2];
-            y[0] = tt[a][0] + tt[a][1] + tt[a][2] + bias;
-            y[1] = tt[a][1] - tt[a][2] - tt[a][3] + bias;
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int soff = (((h * 4 + a) * p.W + i * 2 + dx) * ld) * 4;   // uniform
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(y[dx][i], act)), o_rsrc, o_lane, soff, 0);
-                }
-        }
-    }
+#undef CCVPE_WINO_ROFF
+#undef CCVPE_WINO_DECODE
+#undef CCVPE_WINO_WBASE
 }
 
 template <int NW, int NM, int GC>
 static void launch_wino(const ConvParams& p, hipStream_t s) {
-    constexpr size_t lds = (4096 * NM + (8 * NM + 2) * 18 * (GC * 8 + 4)) * sizeof(float);
+    constexpr size_t lds = (4096 * NM * (NM == 1 ? 2 : 1) + (8 * NM + 2) * 18 * (GC * 8 + 4)) * sizeof(float);
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     static bool attr_done = false;
     auto kern = conv_wino_kernel<NW, NM, GC>;
@@ -262,7 +338,9 @@ static void launch_wino(const ConvParams& p, hipStream_t s) {
     }
     const int mblocks = p.B * (p.W >> 4) * (p.H / (8 * NM));
     const int nblocks = (p.wino_n16 + NW - 1) / NW;
-    dim3 grid(mblocks * nblocks, 1, p.splitk > 1 ? p.splitk : 1);
+    // persistent grid: two workgroups per CU (the register budget allows no more) loop over the tiles
+    const int resident = 2 * 256 / (p.splitk > 1 ? p.splitk : 1);
+    dim3 grid(std::min(mblocks * nblocks, std::max(resident, 8)), 1, p.splitk > 1 ? p.splitk : 1);
     hipLaunchKernelGGL(kern, grid, dim3(NW * NM * 64), lds, s, p);
     if (p.splitk > 1) launch_splitk_reduce(p, s);
 }
@@ -270,7 +348,7 @@ static void launch_wino(const ConvParams& p, hipStream_t s) {
 // bm = output pixels per workgroup (32 tiles x 4 pixels per set), bn = output channels per workgroup
 static const WinoTile WINO_TILES[] = {
     {256, 32, "conv_wino_64x32", launch_wino<2, 2, 2>},
-    {128, 48, "conv_wino_32x48", launch_wino<3, 1, 4>},
+    {128, 48, "conv_wino_32x48", launch_wino<3, 1, 2>},
     {128, 64, "conv_wino_32x64", launch_wino<4, 1, 4>},
     {128, 80, "conv_wino_32x80", launch_wino<5, 1, 4>},
     {256, 48, "conv_wino_64x48", launch_wino<3, 2, 2>},
