@@ -202,7 +202,7 @@ struct Plan {
     hipGraphExec_t exec = nullptr;
     int runs = 0;
     ~Plan() { if (exec) (void)hipGraphExecDestroy(exec); }
-    static constexpr size_t SPLITK_FLOATS = 16u << 20;   // 64 MiB: 16 slabs of M*N <= 1M outputs
+    static constexpr size_t SPLITK_FLOATS = 32u << 20;   // 128 MiB: 16 slabs of M*N <= 2M outputs
 
     Tensor alloc(int B_, int H, int W, int C) {
         Tensor t; t.id = (int)size.size(); t.B = B_; t.H = H; t.W = W; t.C = C;
@@ -1164,7 +1164,10 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
             const long long blocks = conv_igemm_tile_blocks(q, t);
             for (int split = 1; split <= 16; split *= 2) {
                 if (split > 1) {   // split-K only where the grid underfills the chip and K is deep enough
-                    if (blocks >= 512 || blocks * split > 2048 || nkt < 4 * split) break;
+                    // (the persistent Winograd grid also splits when the tile count is an awkward multiple of the
+                    // 512 resident workgroups: 640 tiles = 1.25 per workgroup, 4 x 640 quarter-tiles = 5 each)
+                    const bool wino = conv_igemm_tile_is_wino(t);
+                    if (blocks >= (wino ? 2048 : 512) || blocks * split > (wino ? 8192 : 2048) || nkt < 4 * split) break;
                     if ((size_t)split * op.gemm_m * op.gemm_n > Plan::SPLITK_FLOATS) break;
                 }
                 const int cfg = t | (split << 8);
