@@ -24,6 +24,9 @@ static constexpr int DT = T + 4;      // deconv-output tile (halo 2)
 static constexpr int AT = T + 2;      // conv_a-output tile (halo 1)
 static constexpr int XT = DT / 2;     // input tile (10 x 10)
 static constexpr int PS = 20;         // floats per pixel in the D / A tiles (16 + 4 pad: conflict-free b128)
+static constexpr int DSINK = DT + 2;  // sink rows behind the D tile: offset (dy*DT + dx) past row DT*DT stays inside
+static constexpr int AROWS = ((AT * AT + 15) / 16) * 16;   // A tile rows incl. the padding rows of the last m-tile
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int COUT>
 __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
@@ -32,10 +35,10 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
     const int XS = CXP + 4;                // row stride of the X tile and of the deconv weights
     float* Xs = smem;                      // [XT*XT][XS]
     float* Wd = Xs + XT * XT * XS;         // [64][XS]   n = (dy*2+dx)*16 + o
-    const int r0f = max((XT * XT + 64) * XS, AT * AT * PS);   // region 0 must also hold the aliased A tile
-    float* Ds = smem + r0f;                // [DT*DT][PS]
-    float* As = smem;                      // [AT*AT][PS]  (aliases Xs/Wd, dead after the deconv stage)
-    float* Wt = Ds + DT * DT * PS;         // [9][16][COUT]
+    const int r0f = max((XT * XT + 64) * XS, AROWS * PS);   // region 0 must also hold the aliased A tile
+    float* Ds = smem + r0f;                // [DT*DT + DSINK][PS]  (tail rows: sink for the 12 padding rows of the last m-tile)
+    float* As = smem;                      // [AROWS][PS]  (aliases Xs/Wd, dead after the deconv stage; rows >= 324 are a sink)
+    int* dtab = reinterpret_cast<int*>(Ds + (DT * DT + DSINK) * PS);   // [112] X pixel -> float offset of its (dy,dx) = (0,0) D pixel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int X0 = blockIdx.x * T, Y0 = blockIdx.y * T, b = blockIdx.z;
@@ -57,7 +60,11 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
         const int n = i / c4n, c4 = i - n * c4n;
         *reinterpret_cast<f32x4*>(Wd + n * XS + c4 * 4) = *reinterpret_cast<const f32x4*>(p.wd + (size_t)n * CXP + c4 * 4);
     }
-    for (int i = tid; i < 9 * 16 * COUT; i += 256) Wt[i] = p.wt[i];
+    // Index arithmetic on the vector ALU costs matrix-pipe issue slots on gfx950, so the pixel -> LDS offset maps of
+    // the two epilogues are tabulated once (stage 1) or made affine (stage 2); workgroups whose halo lies fully inside
+    // the image (88 % of them) also skip every bounds test.
+    if (tid < 112) dtab[tid] = tid < XT * XT ? ((2 * (tid / XT)) * DT + 2 * (tid % XT)) * PS : DT * DT * PS;
+    const bool interior = Y0 >= 2 && Y0 + T + 2 <= H && X0 >= 2 && X0 + T + 2 <= W;
     // conv_a weights for this lane: B operand of MFMA j at tap t is Wa[n = lane&15][t*16 + 4*(lane>>4) + j]
     f32x4 wa[9];
 #pragma unroll
@@ -94,15 +101,24 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int mt = h2 ? mt1 : mt0;
+                if (mt >= 7) continue;
                 const f32x4 acc = h2 ? acc1 : acc0;
+                const int4 dt = *reinterpret_cast<const int4*>(dtab + mt * 16 + (lane >> 4) * 4);
+                const int dts[4] = {dt.x, dt.y, dt.z, dt.w};
+                float* dsub = Ds + (dy * DT + dx) * PS + (lane & 15);
+                if (interior) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int px = mt * 16 + (lane >> 4) * 4 + r;       // X pixel of this accumulator row
-                    if (px < XT * XT) {
-                        const int dr = 2 * (px / XT) + dy, dc = 2 * (px % XT) + dx;          // position in the D tile
-                        const int gy = Y0 - 2 + dr, gx = X0 - 2 + dc;                        // position in the image
-                        const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                        Ds[(dr * DT + dc) * PS + (lane & 15)] = in ? acc[r] + bd : 0.f;
+                    for (int r = 0; r < 4; ++r) dsub[dts[r]] = acc[r] + bd;     // rows >= 100 land in the sink row
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int px = mt * 16 + (lane >> 4) * 4 + r;       // X pixel of this accumulator row
+                        if (px < XT * XT) {
+                            const int dr = 2 * (px / XT) + dy, dc = 2 * (px % XT) + dx;          // position in the D tile
+                            const int gy = Y0 - 2 + dr, gx = X0 - 2 + dc;                        // position in the image
+                            const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                            dsub[dts[r]] = in ? acc[r] + bd : 0.f;
+                        }
                     }
                 }
             }
@@ -136,14 +152,21 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             const int mt = h2 ? mt1 : mt0;
+            if (mt >= NMT) continue;
             const f32x4 acc = h2 ? acc1 : acc0;
+            float* asub = As + (mt * 16 + (lane >> 4) * 4) * PS + (lane & 15);
+            if (interior) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = mt * 16 + (lane >> 4) * 4 + r;
-                if (q < AT * AT) {
-                    const int gy = Y0 - 1 + q / AT, gx = X0 - 1 + q % AT;
-                    const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                    As[q * PS + (lane & 15)] = in ? fmaxf(acc[r] + ba, 0.f) : 0.f;
+                for (int r = 0; r < 4; ++r) asub[r * PS] = fmaxf(acc[r] + ba, 0.f);     // rows >= 324 are sink rows
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = mt * 16 + (lane >> 4) * 4 + r;
+                    if (q < AT * AT) {
+                        const int gy = Y0 - 1 + q / AT, gx = X0 - 1 + q % AT;
+                        const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                        asub[r * PS] = in ? fmaxf(acc[r] + ba, 0.f) : 0.f;
+                    }
                 }
             }
         }
@@ -152,22 +175,28 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
 
     // ---- stage 3: conv3x3 16->COUT on the VALU, one output pixel per thread, NCHW store ----
     const int oy = tid >> 4, ox = tid & 15;
-    float o[COUT];
+    // channel pairs on v_pk_fma_f32 (half the VALU slots); the weights are uniform and stay in scalar registers
+    f32x2 o2[COUT];
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) o[c] = p.bt[c];
+    for (int c = 0; c < COUT; ++c) o2[c] = f32x2{p.bt[c], 0.f};
+    const float* __restrict__ wt = p.wt;   // [9][16][COUT]
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const float* ap = As + ((oy + t / 3) * AT + ox + t % 3) * PS;
-        const float* wp = Wt + t * 16 * COUT;
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(ap + c4 * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int c = 0; c < COUT; ++c) o[c] = fmaf(v[e], wp[(c4 * 4 + e) * COUT + c], o[c]);
+            for (int c = 0; c < COUT; ++c) {
+                const float* wp = wt + (t * 16 + c4 * 4) * COUT + c;
+                o2[c] = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{wp[0], wp[COUT]}, o2[c]);
+                o2[c] = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{wp[2 * COUT], wp[3 * COUT]}, o2[c]);
+            }
         }
     }
+    float o[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) o[c] = o2[c].x + o2[c].y;
     const size_t hw = (size_t)H * W;
     const size_t opix = (size_t)(Y0 + oy) * W + X0 + ox;
     if (p.raw) {
@@ -188,8 +217,9 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
 
 size_t level1_lds_bytes(int cxp, int cout) {
     const int XS = cxp + 4;
-    const size_t r0f = std::max<size_t>((size_t)(XT * XT + 64) * XS, (size_t)AT * AT * PS);
-    return (r0f + (size_t)DT * DT * PS + 9 * 16 * cout) * sizeof(float);
+    const size_t r0f = std::max<size_t>((size_t)(XT * XT + 64) * XS, (size_t)AROWS * PS);
+    (void)cout;
+    return (r0f + (size_t)(DT * DT + DSINK) * PS + 112) * sizeof(float);
 }
 
 void launch_level1(const Level1Params& p, hipStream_t s) {
