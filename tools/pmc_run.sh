@@ -1,18 +1,18 @@
 #!/bin/bash
 # Dev tool (GPU box): rocprofv3 --pmc passes on one conv launch.  usage: tools/pmc_run.sh <outdir> <pmc_conv.py args...>
-# Separate passes (the SQ, LDS and TCP counters do not fit one pass); prints the mean per dispatch per counter.
+# Separate passes, --kernel-trace only (never combined with API tracing); prints the mean per dispatch per counter.
+# PMC_SETS (semicolon separated) overrides the default passes.
 out=$1; shift
 export TMPDIR=/tmp
 root=$(pwd)
 mkdir -p "$root/$out"
+sets=${PMC_SETS:-"SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES;FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"}
 i=0
-for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" \
-           "SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" \
-           "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32" \
-           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INSTS_MFMA" \
-           "FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+IFS=';' read -ra arr <<< "$sets"
+for set in "${arr[@]}"; do
   i=$((i+1))
-  (cd /tmp && timeout -k 10 120 rocprofv3 --pmc $set --kernel-trace -d "$root/$out/p$i" -o run --output-format csv -- python3 "$root/tools/pmc_conv.py" "$@" > "$root/$out/p$i.log" 2>&1) || echo "pass $i failed"
+  (cd /tmp && timeout -k 10 150 rocprofv3 --pmc $set --kernel-trace -d "$root/$out/p$i" -o run --output-format csv -- python3 "$root/tools/pmc_conv.py" "$@" > "$root/$out/p$i.log" 2>&1) || echo "pass $i failed"
+  echo "pass $i done: $set"
 done
 python3 - "$root/$out" <<'PY'
 import csv, glob, sys, collections
@@ -26,3 +26,4 @@ for k in sorted(acc):
     v = acc[k]
     print(f"{k:40s} n={len(v):3d} mean={sum(v)/len(v):.4g}")
 PY
+grep -h "TF" "$root/$out"/p1.log | tail -1
