@@ -1127,6 +1127,7 @@ int ccvpe_finalize_weights(ccvpe_handle h) {
     if ((rc = build_decoder(h, h->loc, h->vs.loc, "", 1, true))) return rc;
     if ((rc = build_decoder(h, h->ori, h->vs.ori, "_ori", h->vs.n_rolls, false))) return rc;
     h->host.clear();
+    if (!level1_supported(h->loc.l1_cxp) || !level1_supported(h->ori.l1_cxp)) h->fuse_level1 = false;   // > 64 input channels
     h->finalized = true;
     return 0;
 }

@@ -225,6 +225,7 @@ struct Level1Params {
     float* raw;                // optional un-normalised copy (debug tap)
 };
 void launch_level1(const Level1Params& p, hipStream_t s);
+bool level1_supported(int cxp);   // input channel count the fused kernel takes
 
 struct SoftmaxParams {
     const float* logits;       // [B][n]

@@ -28,203 +28,260 @@ static constexpr int DSINK = DT + 2;  // sink rows behind the D tile: offset (dy
 static constexpr int AROWS = ((AT * AT + 15) / 16) * 16;   // A tile rows incl. the padding rows of the last m-tile
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+static constexpr int KCH_MAX = 4;     // input channels <= 64 (16 per k-chunk); the host falls back to the unfused path beyond
+static constexpr int XI_MAX = (XT * XT * KCH_MAX * 4 + 255) / 256;   // float4 items per thread of one X tile
+
+// Persistent: 2 workgroups per CU loop over the 16x16 output tiles (XCD x owns a contiguous run, so neighbouring
+// tiles - which share their input halo - meet in one L2).  Per-workgroup constants (both weight sets as MFMA B
+// fragments, biases, the pixel -> LDS offset table) are set up once, and the next tile's input pixels are loaded
+// into registers while the current tile runs its three stages.  Measured before this: with one tile per workgroup
+// 0.36 of the 1.06 ms was launch + weight staging + exposed load latency that nothing overlapped.
 template <int COUT>
 __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int CXP = p.cxp;                 // input channels padded to a multiple of 16
-    const int XS = CXP + 4;                // row stride of the X tile and of the deconv weights
+    const int XS = CXP + 4;                // row stride of the X tile
+    const int r0f = max(XT * XT * XS, AROWS * PS);   // region 0 holds the X tile, later the aliased A tile
     float* Xs = smem;                      // [XT*XT][XS]
-    float* Wd = Xs + XT * XT * XS;         // [64][XS]   n = (dy*2+dx)*16 + o
-    const int r0f = max((XT * XT + 64) * XS, AROWS * PS);   // region 0 must also hold the aliased A tile
+    float* As = smem;                      // [AROWS][PS]  (aliases Xs, dead after the deconv stage; rows >= 324 are a sink)
     float* Ds = smem + r0f;                // [DT*DT + DSINK][PS]  (tail rows: sink for the 12 padding rows of the last m-tile)
-    float* As = smem;                      // [AROWS][PS]  (aliases Xs/Wd, dead after the deconv stage; rows >= 324 are a sink)
     int* dtab = reinterpret_cast<int*>(Ds + (DT * DT + DSINK) * PS);   // [112] X pixel -> float offset of its (dy,dx) = (0,0) D pixel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int X0 = blockIdx.x * T, Y0 = blockIdx.y * T, b = blockIdx.z;
     const int H = p.H, W = p.W;            // output size (512); input is H/2 x W/2
     const int IH = H >> 1, IW = W >> 1;
-    const int xr0 = (Y0 >> 1) - 1, xc0 = (X0 >> 1) - 1;
+    const int tiles_x = W / T, tiles_y = H / T;
+    const int tiles = p.B * tiles_x * tiles_y;
+    const int xcd = blockIdx.x & 7;
+    const int stride = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+    const int t_begin = xcd * (tiles >> 3) + min(xcd, tiles & 7);
+    const int t_end = t_begin + (tiles >> 3) + (xcd < (tiles & 7) ? 1 : 0);
+    int tile = t_begin + ((int)blockIdx.x >> 3);
+    if (tile >= t_end) return;
 
-    // ---- stage 0: X tile, deconv weights, tail weights -> LDS ----
-    const int c4n = CXP >> 2;
-    for (int i = tid; i < XT * XT * c4n; i += 256) {
-        const int px = i / c4n, c4 = i - px * c4n;
-        const int xr = xr0 + px / XT, xc = xc0 + px % XT;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)xr < (unsigned)IH && (unsigned)xc < (unsigned)IW && c4 * 4 < p.cx)
-            v = *reinterpret_cast<const f32x4*>(p.x + (((size_t)b * IH + xr) * IW + xc) * p.x_ld + c4 * 4);
-        *reinterpret_cast<f32x4*>(Xs + px * XS + c4 * 4) = v;
-    }
-    for (int i = tid; i < 64 * c4n; i += 256) {
-        const int n = i / c4n, c4 = i - n * c4n;
-        *reinterpret_cast<f32x4*>(Wd + n * XS + c4 * 4) = *reinterpret_cast<const f32x4*>(p.wd + (size_t)n * CXP + c4 * 4);
-    }
+    // ---- once per workgroup ----
     // Index arithmetic on the vector ALU costs matrix-pipe issue slots on gfx950, so the pixel -> LDS offset maps of
-    // the two epilogues are tabulated once (stage 1) or made affine (stage 2); workgroups whose halo lies fully inside
-    // the image (88 % of them) also skip every bounds test.
+    // the two epilogues are tabulated (stage 1) or affine (stage 2); tiles whose halo lies fully inside the image
+    // (88 % of them) also skip every bounds test.
     if (tid < 112) dtab[tid] = tid < XT * XT ? ((2 * (tid / XT)) * DT + 2 * (tid % XT)) * PS : DT * DT * PS;
-    const bool interior = Y0 >= 2 && Y0 + T + 2 <= H && X0 >= 2 && X0 + T + 2 <= W;
+    const int kch = CXP >> 4;
+    // deconv weights: wave w owns output parity (dy,dx) = (w>>1, w&1); B operand of k-chunk kc, MFMA j is
+    // Wd[n = w*16 + (lane&15)][16*kc + 4*(lane>>4) + j]
+    f32x4 wd[KCH_MAX];
+#pragma unroll
+    for (int kc = 0; kc < KCH_MAX; ++kc)
+        wd[kc] = kc < kch ? *reinterpret_cast<const f32x4*>(p.wd + (size_t)(wave * 16 + (lane & 15)) * CXP + kc * 16 + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
     // conv_a weights for this lane: B operand of MFMA j at tap t is Wa[n = lane&15][t*16 + 4*(lane>>4) + j]
     f32x4 wa[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wa[t] = *reinterpret_cast<const f32x4*>(p.wa + (size_t)(lane & 15) * 144 + t * 16 + 4 * (lane >> 4));
     const float bd = p.bd[lane & 15];
     const float ba = p.ba[lane & 15];
-    __syncthreads();
+    const float* __restrict__ wt = p.wt;   // [9][16][COUT], uniform -> scalar loads
 
-    // ---- stage 1: transposed conv as GEMM [100 x CXP] x [CXP x 64]; unit = (m-tile, (dy,dx)) ----
-    // two independent accumulator chains per wave (m-tiles mt and mt+4) hide the 40-cycle dependent-MFMA latency
-    const int kch = CXP >> 4;
-    {
-        const int nt = wave;                       // wave w owns output parity (dy,dx) = (w>>1, w&1)
-        const int dy = nt >> 1, dx = nt & 1;
-        const float* bp = Wd + (nt * 16 + (lane & 15)) * XS + 4 * (lane >> 4);
-        for (int mt0 = 0; mt0 < 7; mt0 += 2) {
-            const int mt1 = mt0 + 1;               // may be 7 (invalid): computed on clamped rows, never stored
-            const float* ap0 = Xs + min(mt0 * 16 + (lane & 15), XT * XT - 1) * XS + 4 * (lane >> 4);
-            const float* ap1 = Xs + min(mt1 * 16 + (lane & 15), XT * XT - 1) * XS + 4 * (lane >> 4);
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            for (int kc = 0; kc < kch; ++kc) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap0 + kc * 16);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap1 + kc * 16);
-                const f32x4 w = *reinterpret_cast<const f32x4*>(bp + kc * 16);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w.z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w.w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w.w, acc1, 0, 0, 0);
-            }
+    // X tile staging: float4 item i = tid + it*256 -> pixel i / c4n, channels 4*(i % c4n)
+    const int c4n = CXP >> 2;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (unsigned)((size_t)p.B * IH * IW * p.x_ld * 4), 0x00020000);
+    int x_lds[XI_MAX], x_rc[XI_MAX];   // LDS float offset (-1: no item), (row << 8 | col) inside the 10x10 tile, channel in bits 16+
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int mt = h2 ? mt1 : mt0;
-                if (mt >= 7) continue;
-                const f32x4 acc = h2 ? acc1 : acc0;
-                const int4 dt = *reinterpret_cast<const int4*>(dtab + mt * 16 + (lane >> 4) * 4);
-                const int dts[4] = {dt.x, dt.y, dt.z, dt.w};
-                float* dsub = Ds + (dy * DT + dx) * PS + (lane & 15);
-                if (interior) {
+    for (int it = 0; it < XI_MAX; ++it) {
+        const int i = tid + it * 256;
+        const int px = i / c4n, c4 = i - px * c4n;
+        const bool live = i < XT * XT * c4n;
+        x_lds[it] = live ? px * XS + c4 * 4 : -1;
+        x_rc[it] = ((px / XT) << 8) | (px % XT) | ((c4 * 4 < p.cx ? c4 * 4 : 0x7fff) << 16);
+    }
+    f32x4 xv[XI_MAX];
+#define CCVPE_L1_LOAD_X(tl)                                                                              \
+    {                                                                                                    \
+        const int b_ = (tl) / (tiles_x * tiles_y);                                                       \
+        const int r_ = (tl) - b_ * (tiles_x * tiles_y);                                                  \
+        const int ty_ = r_ / tiles_x, tx_ = r_ - ty_ * tiles_x;                                          \
+        const int xr0_ = ty_ * (T / 2) - 1, xc0_ = tx_ * (T / 2) - 1;                                    \
+        _Pragma("unroll") for (int it = 0; it < XI_MAX; ++it) {                                          \
+            const int xr = xr0_ + ((x_rc[it] >> 8) & 0xff), xc = xc0_ + (x_rc[it] & 0xff), ch = x_rc[it] >> 16; \
+            const bool ok = x_lds[it] >= 0 && (unsigned)xr < (unsigned)IH && (unsigned)xc < (unsigned)IW && ch != 0x7fff; \
+            const unsigned off = ok ? (unsigned)((((b_ * IH + xr) * IW + xc) * p.x_ld + ch) * 4) : 0x80000000u; \
+            xv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0)); \
+        }                                                                                                \
+    }
+    CCVPE_L1_LOAD_X(tile);
+
+    const int oy = tid >> 4, ox = tid & 15;      // stage 3: one output pixel per thread
+    const size_t hw = (size_t)H * W;
+    constexpr int NMT = (AT * AT + 15) / 16;   // 21
+
+    while (true) {
+        const int b = tile / (tiles_x * tiles_y);
+        const int rem = tile - b * (tiles_x * tiles_y);
+        const int Y0 = (rem / tiles_x) * T, X0 = (rem % tiles_x) * T;
+        const bool interior = Y0 >= 2 && Y0 + T + 2 <= H && X0 >= 2 && X0 + T + 2 <= W;
+
+        // ---- stage 0: this tile's input pixels registers -> LDS; start fetching the next tile's ----
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dsub[dts[r]] = acc[r] + bd;     // rows >= 100 land in the sink row
-                } else {
+        for (int it = 0; it < XI_MAX; ++it)
+            if (x_lds[it] >= 0) *reinterpret_cast<f32x4*>(Xs + x_lds[it]) = xv[it];
+        __syncthreads();
+        const int tile_n = tile + stride;
+        const bool have_n = tile_n < t_end;
+        if (have_n) { CCVPE_L1_LOAD_X(tile_n); }
+
+        // ---- stage 1: transposed conv as GEMM [100 x CXP] x [CXP x 64]; unit = (m-tile, (dy,dx)) ----
+        // two independent accumulator chains per wave (m-tiles mt and mt+1) hide the dependent-MFMA latency
+        {
+            const int dy = wave >> 1, dx = wave & 1;
+            float* dsub = Ds + (dy * DT + dx) * PS + (lane & 15);
+            for (int mt0 = 0; mt0 < 7; mt0 += 2) {
+                const int mt1 = mt0 + 1;               // may be 7 (invalid): computed on clamped rows, never stored
+                const float* ap0 = Xs + min(mt0 * 16 + (lane & 15), XT * XT - 1) * XS + 4 * (lane >> 4);
+                const float* ap1 = Xs + min(mt1 * 16 + (lane & 15), XT * XT - 1) * XS + 4 * (lane >> 4);
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int px = mt * 16 + (lane >> 4) * 4 + r;       // X pixel of this accumulator row
-                        if (px < XT * XT) {
-                            const int dr = 2 * (px / XT) + dy, dc = 2 * (px % XT) + dx;          // position in the D tile
-                            const int gy = Y0 - 2 + dr, gx = X0 - 2 + dc;                        // position in the image
-                            const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                            dsub[dts[r]] = in ? acc[r] + bd : 0.f;
+                for (int kc = 0; kc < KCH_MAX; ++kc) {
+                    if (kc >= kch) break;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap0 + kc * 16);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap1 + kc * 16);
+                    const f32x4 w = wd[kc];
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w.w, acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int mt = h2 ? mt1 : mt0;
+                    if (mt >= 7) continue;
+                    const f32x4 acc = h2 ? acc1 : acc0;
+                    const int4 dt = *reinterpret_cast<const int4*>(dtab + mt * 16 + (lane >> 4) * 4);
+                    const int dts[4] = {dt.x, dt.y, dt.z, dt.w};
+                    if (interior) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dsub[dts[r]] = acc[r] + bd;     // rows >= 100 land in the sink rows
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int px = mt * 16 + (lane >> 4) * 4 + r;       // X pixel of this accumulator row
+                            if (px < XT * XT) {
+                                const int dr = 2 * (px / XT) + dy, dc = 2 * (px % XT) + dx;          // position in the D tile
+                                const int gy = Y0 - 2 + dr, gx = X0 - 2 + dc;                        // position in the image
+                                const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                                dsub[dts[r]] = in ? acc[r] + bd : 0.f;
+                            }
                         }
                     }
                 }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- stage 2: conv3x3 16->16 + ReLU on the 18x18 halo tile: 21 m-tiles of 16 pixels, 36 MFMAs each ----
-    constexpr int NMT = (AT * AT + 15) / 16;   // 21
-    for (int mt0 = wave; mt0 < NMT; mt0 += 8) {
-        const int mt1 = mt0 + 4;                   // second chain (may be >= NMT: clamped reads, no stores)
-        const int pa0 = min(mt0 * 16 + (lane & 15), AT * AT - 1);
-        const int pa1 = min(mt1 * 16 + (lane & 15), AT * AT - 1);
-        const float* dp0 = Ds + ((pa0 / AT) * DT + pa0 % AT) * PS + 4 * (lane >> 4);
-        const float* dp1 = Ds + ((pa1 / AT) * DT + pa1 % AT) * PS + 4 * (lane >> 4);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // ---- stage 2: conv3x3 16->16 + ReLU on the 18x18 halo tile: 21 m-tiles of 16 pixels, 36 MFMAs each ----
+        for (int mt0 = wave; mt0 < NMT; mt0 += 8) {
+            const int mt1 = mt0 + 4;                   // second chain (may be >= NMT: clamped reads, no stores)
+            const int pa0 = min(mt0 * 16 + (lane & 15), AT * AT - 1);
+            const int pa1 = min(mt1 * 16 + (lane & 15), AT * AT - 1);
+            const float* dp0 = Ds + ((pa0 / AT) * DT + pa0 % AT) * PS + 4 * (lane >> 4);
+            const float* dp1 = Ds + ((pa1 / AT) * DT + pa1 % AT) * PS + 4 * (lane >> 4);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int toff = ((t / 3) * DT + (t % 3)) * PS;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(dp0 + toff);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(dp1 + toff);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wa[t].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wa[t].x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wa[t].y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wa[t].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wa[t].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wa[t].z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wa[t].w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wa[t].w, acc1, 0, 0, 0);
-        }
+            for (int t = 0; t < 9; ++t) {
+                const int toff = ((t / 3) * DT + (t % 3)) * PS;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(dp0 + toff);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(dp1 + toff);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wa[t].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wa[t].x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wa[t].y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wa[t].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wa[t].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wa[t].z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wa[t].w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wa[t].w, acc1, 0, 0, 0);
+            }
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int mt = h2 ? mt1 : mt0;
-            if (mt >= NMT) continue;
-            const f32x4 acc = h2 ? acc1 : acc0;
-            float* asub = As + (mt * 16 + (lane >> 4) * 4) * PS + (lane & 15);
-            if (interior) {
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int mt = h2 ? mt1 : mt0;
+                if (mt >= NMT) continue;
+                const f32x4 acc = h2 ? acc1 : acc0;
+                float* asub = As + (mt * 16 + (lane >> 4) * 4) * PS + (lane & 15);
+                if (interior) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) asub[r * PS] = fmaxf(acc[r] + ba, 0.f);     // rows >= 324 are sink rows
-            } else {
+                    for (int r = 0; r < 4; ++r) asub[r * PS] = fmaxf(acc[r] + ba, 0.f);     // rows >= 324 are sink rows
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = mt * 16 + (lane >> 4) * 4 + r;
-                    if (q < AT * AT) {
-                        const int gy = Y0 - 1 + q / AT, gx = X0 - 1 + q % AT;
-                        const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                        asub[r * PS] = in ? fmaxf(acc[r] + ba, 0.f) : 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = mt * 16 + (lane >> 4) * 4 + r;
+                        if (q < AT * AT) {
+                            const int gy = Y0 - 1 + q / AT, gx = X0 - 1 + q % AT;
+                            const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                            asub[r * PS] = in ? fmaxf(acc[r] + ba, 0.f) : 0.f;
+                        }
                     }
                 }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- stage 3: conv3x3 16->COUT on the VALU, one output pixel per thread, NCHW store ----
-    const int oy = tid >> 4, ox = tid & 15;
-    // channel pairs on v_pk_fma_f32 (half the VALU slots); the weights are uniform and stay in scalar registers
-    f32x2 o2[COUT];
+        // ---- stage 3: conv3x3 16->COUT on the VALU, one output pixel per thread, NCHW store ----
+        // channel pairs on v_pk_fma_f32 (half the VALU slots); the weights are uniform and stay in scalar registers
+        f32x2 o2[COUT];
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) o2[c] = f32x2{p.bt[c], 0.f};
-    const float* __restrict__ wt = p.wt;   // [9][16][COUT]
+        for (int c = 0; c < COUT; ++c) o2[c] = f32x2{p.bt[c], 0.f};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const float* ap = As + ((oy + t / 3) * AT + ox + t % 3) * PS;
+        for (int t = 0; t < 9; ++t) {
+            const float* ap = As + ((oy + t / 3) * AT + ox + t % 3) * PS;
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ap + c4 * 4);
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap + c4 * 4);
 #pragma unroll
-            for (int c = 0; c < COUT; ++c) {
-                const float* wp = wt + (t * 16 + c4 * 4) * COUT + c;
-                o2[c] = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{wp[0], wp[COUT]}, o2[c]);
-                o2[c] = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{wp[2 * COUT], wp[3 * COUT]}, o2[c]);
+                for (int c = 0; c < COUT; ++c) {
+                    const float* wp = wt + (t * 16 + c4 * 4) * COUT + c;
+                    o2[c] = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{wp[0], wp[COUT]}, o2[c]);
+                    o2[c] = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{wp[2 * COUT], wp[3 * COUT]}, o2[c]);
+                }
             }
         }
+        float o[COUT];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) o[c] = o2[c].x + o2[c].y;
+        const size_t opix = (size_t)(Y0 + oy) * W + X0 + ox;
+        if (p.raw) {
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) p.raw[((size_t)b * COUT + c) * hw + opix] = o[c];
+        }
+        if (p.normalize) {
+            float n2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) n2 = fmaf(o[c], o[c], n2);
+            const float inv = 1.f / fmaxf(sqrtf(n2), 1e-12f);
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) o[c] *= inv;
+        }
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) p.out[((size_t)b * COUT + c) * hw + opix] = o[c];
+
+        if (!have_n) break;
+        __syncthreads();   // the A tile (aliasing Xs) is fully consumed before the next X tile lands
+        tile = tile_n;
     }
-    float o[COUT];
-#pragma unroll
-    for (int c = 0; c < COUT; ++c) o[c] = o2[c].x + o2[c].y;
-    const size_t hw = (size_t)H * W;
-    const size_t opix = (size_t)(Y0 + oy) * W + X0 + ox;
-    if (p.raw) {
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) p.raw[((size_t)b * COUT + c) * hw + opix] = o[c];
-    }
-    if (p.normalize) {
-        float n2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) n2 = fmaf(o[c], o[c], n2);
-        const float inv = 1.f / fmaxf(sqrtf(n2), 1e-12f);
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) o[c] *= inv;
-    }
-#pragma unroll
-    for (int c = 0; c < COUT; ++c) p.out[((size_t)b * COUT + c) * hw + opix] = o[c];
+#undef CCVPE_L1_LOAD_X
 }
+
+bool level1_supported(int cxp) { return cxp >= 16 && cxp <= 16 * KCH_MAX && cxp % 16 == 0; }
 
 size_t level1_lds_bytes(int cxp, int cout) {
     const int XS = cxp + 4;
-    const size_t r0f = std::max<size_t>((size_t)(XT * XT + 64) * XS, (size_t)AROWS * PS);
+    const size_t r0f = std::max<size_t>((size_t)XT * XT * XS, (size_t)AROWS * PS);
     (void)cout;
     return (r0f + (size_t)(DT * DT + DSINK) * PS + 112) * sizeof(float);
 }
 
 void launch_level1(const Level1Params& p, hipStream_t s) {
     const size_t lds = level1_lds_bytes(p.cxp, p.cout);
-    dim3 grid(p.W / T, p.H / T, p.B);
+    const int tiles = (p.W / T) * (p.H / T) * p.B;
+    dim3 grid(std::min(tiles, 2 * 256));   // persistent: two workgroups per CU
     if (p.cout == 1) {
         static size_t set1 = 0;
         if (lds > set1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(level1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set1 = lds; }
