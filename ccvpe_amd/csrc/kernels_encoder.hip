@@ -75,16 +75,20 @@ void launch_stem(const StemParams& p, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // Depthwise k x k (k = 3 | 5), stride 1 | 2, static zero / horizontal-circular padding, BN + swish,
 // plus per-(sample, strip-lane, channel) partial sums for the squeeze-excite average pool.
-// thread = (4 channels, strip of TX output pixels along x); the k + (TX-1)*stride input columns of a
-// strip are loaded once per filter row and reused across the TX outputs.  A thread walks strips
-// lane, lane+S, ... of one sample, so its pooled partial sum is private and deterministic.
+// thread = (4 channels, patch of TX x TY output pixels).  The thread keeps its k*k filter taps (4 channels each)
+// in registers for all the patches it walks, and every input row of a patch (k + (TX-1)*stride columns) is
+// loaded once and feeds all the output rows it contributes to: 48 16-byte loads per 8 outputs for 5x5 / s1
+// instead of 130 (the kernel is bound by the load path, not by HBM).  A thread walks patches lane, lane+S, ...
+// of one sample, so its pooled partial sum is private and deterministic; the per-output FMA order (ky, kx
+// ascending) is the same as a plain loop nest.
 // ------------------------------------------------------------------------------------------------
-template <int K, int STRIDE, int TX>
+template <int K, int STRIDE, int TX, int TY>
 __global__ __launch_bounds__(256) void depthwise_kernel(const DwParams p) {
     constexpr int NCOL = K + (TX - 1) * STRIDE;
+    constexpr int NROW = K + (TY - 1) * STRIDE;
     const int cg_n = p.C >> 2;
     const int sx_n = (p.OW + TX - 1) / TX;
-    const int nstrips = p.OH * sx_n;
+    const int nstrips = ((p.OH + TY - 1) / TY) * sx_n;
     const long long total = (long long)p.B * p.S * cg_n;
     for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
         const int cg = (int)(it % cg_n);
@@ -93,19 +97,25 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const DwParams p) {
         const int b = (int)(t / p.S);
         const int c0 = cg * 4;
         const float4 bias = *reinterpret_cast<const float4*>(p.bias + c0);
+        float4 w[K * K];
+#pragma unroll
+        for (int i = 0; i < K * K; ++i) w[i] = *reinterpret_cast<const float4*>(p.w + i * p.C + c0);
         float4 pool = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* inb = p.in + (size_t)b * p.H * p.W * p.C + c0;
         float* outb = p.out + (size_t)b * p.OH * p.OW * p.C + c0;
         for (int strip = lane_s; strip < nstrips; strip += p.S) {
-            const int oy = strip / sx_n;
-            const int ox0 = (strip - oy * sx_n) * TX;
-            float4 acc[TX];
+            const int sy = strip / sx_n;
+            const int oy0 = sy * TY;
+            const int ox0 = (strip - sy * sx_n) * TX;
+            float4 acc[TY][TX];
 #pragma unroll
-            for (int i = 0; i < TX; ++i) acc[i] = bias;
+            for (int j = 0; j < TY; ++j)
+#pragma unroll
+                for (int i = 0; i < TX; ++i) acc[j][i] = bias;
             const int ix0 = ox0 * STRIDE - p.pad_l;
 #pragma unroll
-            for (int ky = 0; ky < K; ++ky) {
-                const int iy = oy * STRIDE - p.pad_t + ky;
+            for (int r = 0; r < NROW; ++r) {
+                const int iy = oy0 * STRIDE - p.pad_t + r;
                 if ((unsigned)iy >= (unsigned)p.H) continue;
                 const float* row = inb + (size_t)iy * p.W * p.C;
                 float4 col[NCOL];
@@ -116,45 +126,53 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const DwParams p) {
                     if (p.circular) {
                         if (ix < 0) ix += p.W;
                         else if (ix >= p.W) ix -= p.W;
-                        ok = (unsigned)ix < (unsigned)p.W;   // strips past the right edge
+                        ok = (unsigned)ix < (unsigned)p.W;   // patches past the right edge
                     } else {
                         ok = (unsigned)ix < (unsigned)p.W;
                     }
                     col[j] = ok ? *reinterpret_cast<const float4*>(row + (size_t)ix * p.C) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
-                for (int kx = 0; kx < K; ++kx) {
-                    const float4 w = *reinterpret_cast<const float4*>(p.w + (ky * K + kx) * p.C + c0);
+                for (int ty = 0; ty < TY; ++ty) {
+                    const int ky = r - ty * STRIDE;      // compile-time after unrolling
+                    if (ky < 0 || ky >= K) continue;
 #pragma unroll
-                    for (int i = 0; i < TX; ++i) {
-                        const float4 v = col[i * STRIDE + kx];
-                        acc[i].x = fmaf(v.x, w.x, acc[i].x);
-                        acc[i].y = fmaf(v.y, w.y, acc[i].y);
-                        acc[i].z = fmaf(v.z, w.z, acc[i].z);
-                        acc[i].w = fmaf(v.w, w.w, acc[i].w);
+                    for (int kx = 0; kx < K; ++kx) {
+                        const float4 wv = w[ky * K + kx];
+#pragma unroll
+                        for (int i = 0; i < TX; ++i) {
+                            const float4 v = col[i * STRIDE + kx];
+                            acc[ty][i].x = fmaf(v.x, wv.x, acc[ty][i].x);
+                            acc[ty][i].y = fmaf(v.y, wv.y, acc[ty][i].y);
+                            acc[ty][i].z = fmaf(v.z, wv.z, acc[ty][i].z);
+                            acc[ty][i].w = fmaf(v.w, wv.w, acc[ty][i].w);
+                        }
                     }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < TX; ++i) {
-                if (ox0 + i < p.OW) {
-                    float4 o;
-                    o.x = swishf(acc[i].x); o.y = swishf(acc[i].y); o.z = swishf(acc[i].z); o.w = swishf(acc[i].w);
-                    pool.x += o.x; pool.y += o.y; pool.z += o.z; pool.w += o.w;
-                    *reinterpret_cast<float4*>(outb + ((size_t)oy * p.OW + ox0 + i) * p.C) = o;
+            for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+                for (int i = 0; i < TX; ++i) {
+                    if (oy0 + ty < p.OH && ox0 + i < p.OW) {
+                        float4 o;
+                        o.x = swishf(acc[ty][i].x); o.y = swishf(acc[ty][i].y); o.z = swishf(acc[ty][i].z); o.w = swishf(acc[ty][i].w);
+                        pool.x += o.x; pool.y += o.y; pool.z += o.z; pool.w += o.w;
+                        *reinterpret_cast<float4*>(outb + ((size_t)(oy0 + ty) * p.OW + ox0 + i) * p.C) = o;
+                    }
                 }
-            }
         }
         *reinterpret_cast<float4*>(p.pool_partial + ((size_t)b * p.S + lane_s) * p.C + c0) = pool;
     }
 }
 
 static constexpr int DW_TX = 4;
+static constexpr int DW_TY = 2;
 
 int depthwise_strip_lanes(int B, int OH, int OW, int C) {
     const int sx_n = (OW + DW_TX - 1) / DW_TX;
-    const int nstrips = OH * sx_n;
-    const long long target = 256LL * 2048;   // ~8 waves per SIMD over the chip
+    const int nstrips = ((OH + DW_TY - 1) / DW_TY) * sx_n;
+    const long long target = 256LL * 1024;   // ~4 waves per SIMD over the chip (the kernel holds ~170 VGPRs)
     long long s = target / ((long long)B * (C / 4));
     if (s < 1) s = 1;
     if (s > nstrips) s = nstrips;
@@ -164,10 +182,10 @@ int depthwise_strip_lanes(int B, int OH, int OW, int C) {
 void launch_depthwise(const DwParams& p, hipStream_t s) {
     long long total = (long long)p.B * p.S * (p.C / 4);
     int blocks = (int)((total + 255) / 256);
-    if (p.k == 3 && p.stride == 1) hipLaunchKernelGGL((depthwise_kernel<3, 1, DW_TX>), dim3(blocks), dim3(256), 0, s, p);
-    else if (p.k == 3 && p.stride == 2) hipLaunchKernelGGL((depthwise_kernel<3, 2, DW_TX>), dim3(blocks), dim3(256), 0, s, p);
-    else if (p.k == 5 && p.stride == 1) hipLaunchKernelGGL((depthwise_kernel<5, 1, DW_TX>), dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((depthwise_kernel<5, 2, DW_TX>), dim3(blocks), dim3(256), 0, s, p);
+    if (p.k == 3 && p.stride == 1) hipLaunchKernelGGL((depthwise_kernel<3, 1, DW_TX, DW_TY>), dim3(blocks), dim3(256), 0, s, p);
+    else if (p.k == 3 && p.stride == 2) hipLaunchKernelGGL((depthwise_kernel<3, 2, DW_TX, DW_TY>), dim3(blocks), dim3(256), 0, s, p);
+    else if (p.k == 5 && p.stride == 1) hipLaunchKernelGGL((depthwise_kernel<5, 1, DW_TX, DW_TY>), dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((depthwise_kernel<5, 2, DW_TX, DW_TY>), dim3(blocks), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
