@@ -600,7 +600,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         const bool fused = b.e != 1 && bw.exp_lin != nullptr &&
                            (h->fuse_mbconv == 2 || (h->fuse_mbconv == 1 && mbconv_front_profitable(b.k)));
         Tensor d = pl.alloc(B, oh, ow, mid);
-        const int S = fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid);
+        const int S = fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid, b.k, b.s);
         Tensor pool = pl.alloc(B, 1, S, mid);
         if (fused) {
             MbFrontParams mp{};

@@ -121,7 +121,7 @@ struct DwParams {
     int S;                     // strip lanes per sample
 };
 void launch_depthwise(const DwParams& p, hipStream_t s);
-int depthwise_strip_lanes(int B, int OH, int OW, int C);
+int depthwise_strip_lanes(int B, int OH, int OW, int C, int k, int stride);
 
 // Fused expand (1x1 + BN + swish) + depthwise (k x k + BN + swish) + SE pooling partials (kernels_mbconv.hip)
 struct MbFrontParams {
