@@ -179,6 +179,11 @@ struct Op {
     int gemm_m = 0, gemm_n = 0, gemm_kpad = 0;
     bool bf16x3_only = false;     // the launch reads a pre-split bf16 tensor: exact-fp32 tiles cannot serve it
     bool wino_ok = false;         // 3x3 / stride 1 layer with Winograd-domain weights packed
+    // two-stream execution (Plan::schedule): stream the op is issued on, ops of the other stream it must wait for,
+    // and whether an op of the other stream waits for this one (then an event is recorded after it)
+    int stream = 0;
+    std::vector<int> wait_on;
+    bool signal = false;
 };
 
 struct TapInfo { Tensor t; int coff; int C; };
@@ -201,7 +206,38 @@ struct Plan {
     Tensor tune_cache;            // encode plans: stand-in for the caller's cache while the plan is being autotuned
     hipGraphExec_t exec = nullptr;
     int runs = 0;
-    ~Plan() { if (exec) (void)hipGraphExecDestroy(exec); }
+    // Two-stream execution: the aerial encoder and the orientation decoder are issued on a second stream, so the
+    // ramp-up / drain of the ~330 short kernels of one chain is filled by the other chain.  Dependencies come from
+    // the ops' tensor lists (any two ops that touch the same tensor stay ordered), and a two-stream plan gives every
+    // tensor its own memory (lifetime-based reuse would add hidden dependencies between the streams).
+    bool two_streams = false;
+    Tensor scratch2;              // split-K slab scratch of the second stream
+    std::vector<hipEvent_t> events;   // one per signalling op + fork + join, created on first use
+    ~Plan() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e);
+    }
+    void schedule() {
+        if (!two_streams) return;
+        bool any = false;
+        for (auto& o : ops) {
+            o.stream = (o.name.rfind("sat.", 0) == 0 || o.name.rfind("ori", 0) == 0) ? 1 : 0;
+            any = any || o.stream == 1;
+            o.wait_on.clear();
+            o.signal = false;
+        }
+        if (!any) { two_streams = false; return; }
+        std::map<int, int> last_use;   // tensor id -> most recent op that touches it
+        for (int i = 0; i < (int)ops.size(); ++i) {
+            int dep = -1;              // stream order already covers earlier ops of a stream: the latest one is enough
+            for (int id : ops[i].uses) {
+                auto it = last_use.find(id);
+                if (it != last_use.end() && ops[it->second].stream != ops[i].stream) dep = std::max(dep, it->second);
+            }
+            if (dep >= 0) { ops[i].wait_on.push_back(dep); ops[dep].signal = true; }
+            for (int id : ops[i].uses) last_use[id] = i;
+        }
+    }
     static constexpr size_t SPLITK_FLOATS = 32u << 20;   // 128 MiB: 16 slabs of M*N <= 2M outputs
 
     Tensor alloc(int B_, int H, int W, int C) {
@@ -228,8 +264,9 @@ struct Plan {
         std::vector<int> first(n, 1 << 30), last(n, -1);
         for (int i = 0; i < (int)ops.size(); ++i)
             for (int id : ops[i].uses) { first[id] = std::min(first[id], i); last[id] = std::max(last[id], i); }
-        if (debug) for (int i = 0; i < n; ++i) last[i] = 1 << 30;
+        if (debug || two_streams) for (int i = 0; i < n; ++i) last[i] = 1 << 30;
         if (scratch.id >= 0) { first[scratch.id] = 0; last[scratch.id] = 1 << 30; }
+        if (scratch2.id >= 0) { first[scratch2.id] = 0; last[scratch2.id] = 1 << 30; }
         if (tune_cache.id >= 0) { first[tune_cache.id] = 0; last[tune_cache.id] = 1 << 30; }
         if (use_graph)
             for (const Tensor* t : {&io_grd, &io_sat, &io_logits, &io_heat, &io_ori, &io_ms[0], &io_ms[1], &io_ms[2], &io_ms[3], &io_ms[4], &io_ms[5]}) {
@@ -276,6 +313,8 @@ struct ccvpe_handle_s {
     bool wino = true;             // CCVPE_WINOGRAD=0 keeps the decoder 3x3 layers on the implicit GEMM
     int graph_mode = -1;          // -1 auto (plans of <= 4 samples replay a hipGraph), 0 never, 1 always
     hipStream_t capture_stream = nullptr;
+    hipStream_t aux_stream = nullptr;   // second stream of two-stream plans
+    bool two_streams = true;      // CCVPE_STREAMS=1 issues everything on the caller's stream
     std::vector<void*> dev_allocs;
     EncoderW grd_enc, sat_enc;
     PackedConv grd_heads, sat_desc;
@@ -703,6 +742,8 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
     const VariantSpec& vs = h->vs;
     pl.B = B; pl.gh = gh; pl.gw = gw; pl.debug = h->debug;
     pl.scratch = pl.alloc(1, 1, 1, (int)Plan::SPLITK_FLOATS);
+    pl.two_streams = h->two_streams && !h->debug;
+    if (pl.two_streams) pl.scratch2 = pl.alloc(1, 1, 1, (int)Plan::SPLITK_FLOATS);
     pl.use_graph = !cached && (h->graph_mode == 1 || (h->graph_mode < 0 && B <= 4));
     if (pl.use_graph) {
         pl.io_grd = pl.alloc(B, 3, gh, gw);
@@ -968,6 +1009,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
         }, 2.0 * B * 262144.0 * 288, 4.0 * B * 262144.0 * 18);
         }
     }
+    pl.schedule();
     pl.assign();
     return 0;
 }
@@ -1032,6 +1074,7 @@ int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
     if (const char* e = getenv("CCVPE_GRAPH")) h->graph_mode = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_FUSE_L1")) h->fuse_level1 = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_WINOGRAD")) h->wino = std::atoi(e) != 0;
+    if (const char* e = getenv("CCVPE_STREAMS")) h->two_streams = std::atoi(e) >= 2;
     if (const char* e = getenv("CCVPE_FUSE_MBCONV")) h->fuse_mbconv = std::atoi(e);
     if (const char* e = getenv("CCVPE_PRECISION")) h->cfg.reserved[0] = (std::string(e) == "bf16x3") ? 1 : 0;
     if (h->cfg.reserved[0] != 0 && h->cfg.reserved[0] != 1) { delete h; return fail(CCVPE_EINVAL, "unknown precision mode %d", cfg->reserved[0]); }
@@ -1054,6 +1097,7 @@ int ccvpe_destroy(ccvpe_handle h) {
     if (h->arena) (void)hipFree(h->arena);
     h->plans.clear();
     if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     delete h;
     return 0;
 }
@@ -1233,6 +1277,41 @@ size_t ccvpe_workspace_bytes(ccvpe_handle h, int32_t batch, int32_t grd_h, int32
     return pl.total * sizeof(float);
 }
 
+// Issue a plan's ops: in order on one stream, or on two streams with event edges for the cross-stream dependencies.
+static int run_ops(ccvpe_handle h, Plan& pl, const Ctx& base, hipStream_t s0) {
+    if (!pl.two_streams) {
+        Ctx c = base;
+        c.stream = s0;
+        for (auto& op : pl.ops) op.fn(c);
+        base.conv_errors += c.conv_errors;
+        return 0;
+    }
+    if (!h->aux_stream) HIPCHK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    if (pl.events.empty()) {
+        pl.events.assign(pl.ops.size() + 2, nullptr);
+        for (size_t i = 0; i < pl.events.size(); ++i)
+            if (i >= pl.ops.size() || pl.ops[i].signal) HIPCHK(hipEventCreateWithFlags(&pl.events[i], hipEventDisableTiming));
+    }
+    Ctx c[2] = {base, base};
+    hipStream_t st[2] = {s0, h->aux_stream};
+    c[0].stream = st[0];
+    c[1].stream = st[1];
+    c[1].splitk_scratch = c[1].ptr(pl.scratch2);
+    const size_t n = pl.ops.size();
+    HIPCHK(hipEventRecord(pl.events[n], st[0]));            // fork: the second stream starts after the caller's prior work
+    HIPCHK(hipStreamWaitEvent(st[1], pl.events[n], 0));
+    for (size_t i = 0; i < n; ++i) {
+        Op& op = pl.ops[i];
+        for (int d : op.wait_on) HIPCHK(hipStreamWaitEvent(st[op.stream], pl.events[d], 0));
+        op.fn(c[op.stream]);
+        if (op.signal) HIPCHK(hipEventRecord(pl.events[i], st[op.stream]));
+    }
+    HIPCHK(hipEventRecord(pl.events[n + 1], st[1]));        // join
+    HIPCHK(hipStreamWaitEvent(st[0], pl.events[n + 1], 0));
+    base.conv_errors += c[0].conv_errors + c[1].conv_errors;
+    return 0;
+}
+
 static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const float* sat, int batch,
                        const ccvpe_outputs* out, hipStream_t stream, bool profile, const float* cache = nullptr) {
     const int mode = cache ? 2 : 0;
@@ -1284,10 +1363,9 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
                 hipGraph_t graph = nullptr;
                 if (!h->capture_stream) HIPCHK(hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking));
                 HIPCHK(hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeThreadLocal));
-                Ctx cc = c;
-                cc.stream = h->capture_stream;
-                for (auto& op : pl->ops) op.fn(cc);
+                const int rrc = run_ops(h, *pl, c, h->capture_stream);
                 hipError_t ce = hipStreamEndCapture(h->capture_stream, &graph);
+                if (rrc) ce = hipErrorUnknown;
                 if (ce == hipSuccess && graph) {
                     hipGraphExec_t ex = nullptr;
                     if (hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0) == hipSuccess) pl->exec = ex;
@@ -1296,7 +1374,7 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
                 if (!pl->exec) { (void)hipGetLastError(); pl->use_graph = false; }   // fall back to eager launches for good
             }
             if (pl->exec) HIPCHK(hipGraphLaunch(pl->exec, stream));
-            else for (auto& op : pl->ops) op.fn(c);
+            else if (int rrc = run_ops(h, *pl, c, stream)) return rrc;
             pl->runs++;
             HIPCHK(hipMemcpyAsync(user.logits_flattened, c.out.logits_flattened, (size_t)mb * npx * sizeof(float), hipMemcpyDeviceToDevice, stream));
             HIPCHK(hipMemcpyAsync(user.heatmap, c.out.heatmap, (size_t)mb * npx * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -1306,7 +1384,7 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
                 HIPCHK(hipMemcpyAsync(user.matching_score[k], c.out.matching_score[k], (size_t)mb * h->rolls[k] * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
             }
         } else if (!profile) {
-            for (auto& op : pl->ops) op.fn(c);
+            if (int rrc = run_ops(h, *pl, c, stream)) return rrc;
         } else {
             hipEvent_t e0, e1;
             HIPCHK(hipEventCreate(&e0));
