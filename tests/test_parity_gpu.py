@@ -184,3 +184,25 @@ def test_bf16x3_mode_stays_inside_the_contract(name):
     assert worst <= CONTRACT_RTOL
     post = m.postprocess(outs[1], outs[2])
     assert np.array_equal(post["index"].cpu().numpy(), fx["post/index"])
+
+
+@pytest.mark.parametrize("batch", [1, 6])
+def test_two_stream_schedule_is_bitwise_identical_to_single_stream(monkeypatch, batch):
+    """The second stream (aerial encoder, orientation decoder) only changes WHEN kernels run: with the tile choice
+    pinned (no autotune) every output must be bit-identical to the single-stream issue order, for the eager path
+    (batch 6) and the hipGraph replay path (batch 1, run three times so the captured graph is the one compared)."""
+    cfg = gu.CONFIGS["vigor_prior180_circ"]
+    g, s = inputs(cfg, batch=batch)
+    monkeypatch.setenv("CCVPE_AUTOTUNE", "0")
+    results = []
+    for streams in ("1", "2"):
+        monkeypatch.setenv("CCVPE_STREAMS", streams)
+        m = build_model(cfg)
+        outs = None
+        for _ in range(3):
+            outs = m(g, s)
+        torch.cuda.synchronize()
+        results.append([o.clone() for o in outs])
+        del m
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
