@@ -45,18 +45,30 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// n / d for 0 <= n < 2^31 with the host-made (mul, shift) pair of conv_igemm_prepare (runtime integer division
+// costs ~25 VALU instructions; the pixel shuffle of a transposed conv needs four per 16-byte store)
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shift) {
+    return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> shift);
+}
+
+// pixel-shuffle address of GEMM row m, column group q = (dy, dx) of a k2 s2 transposed conv
+__device__ __forceinline__ int deconv_pixel(const ConvParams& p, int m, int q) {
+    const int t = fast_div(m, p.fdw_mul, p.fdw_shift);
+    const int x = m - t * p.W;
+    const int b = fast_div(t, p.fdh_mul, p.fdh_shift);
+    const int y = t - b * p.H;
+    return (b * 2 * p.H + 2 * y + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
+}
+
 // Final placement of 4 consecutive output channels (n .. n+3) of GEMM row m: residual add, k2s2
 // pixel-shuffle addressing for the transposed conv, up to 3 concat destinations; 16-byte stores when legal.
 __device__ __forceinline__ void emit_out4(const ConvParams& p, int m, int n, f32x4 v) {
     int opix = m, o = n;
     if (p.mode == MODE_DECONV) {
-        const int q = n / p.deconv_cout;
-        o = n - q * p.deconv_cout;
-        const int x = m % p.W;
-        const int t = m / p.W;
-        const int y = t % p.H;
-        const int b = t / p.H;
-        opix = (b * 2 * p.H + 2 * y + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
+        const int c = p.deconv_cout;
+        const int q = (n >= c) + (n >= 2 * c) + (n >= 3 * c);   // n / deconv_cout, n < 4 * deconv_cout
+        o = n - q * c;
+        opix = deconv_pixel(p, m, q);
     }
     if (p.vec_epi) {
         if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.resid_ld + n);
@@ -83,11 +95,10 @@ __device__ __forceinline__ void emit_out4(const ConvParams& p, int m, int n, f32
             float ve = v[e];
             int oe = o + e, pe = opix;
             if (p.mode == MODE_DECONV) {   // a float4 may straddle two (dy,dx) groups when cout % 4 != 0
-                const int q = (n + e) / p.deconv_cout;
-                oe = (n + e) - q * p.deconv_cout;
-                const int x = m % p.W;
-                const int t = m / p.W;
-                pe = ((t / p.H) * 2 * p.H + 2 * (t % p.H) + (q >> 1)) * (2 * p.W) + 2 * x + (q & 1);
+                const int c = p.deconv_cout;
+                const int q = (n + e >= c) + (n + e >= 2 * c) + (n + e >= 3 * c);
+                oe = (n + e) - q * c;
+                pe = deconv_pixel(p, m, q);
             } else if (p.resid) {
                 ve += p.resid[(size_t)m * p.resid_ld + n + e];
             }

@@ -67,6 +67,8 @@ struct ConvParams {
     int splitk;                // filled by launch_conv_igemm from the cfg word: K split over gridDim.z
     float* partial;            // split-K slab scratch [splitk][M][N] (null = split-K unavailable)
     size_t partial_floats;
+    // exact division by W and H for the transposed-conv pixel shuffle (filled by conv_igemm_prepare): q = (umulhi(n, mul) + n) >> shift
+    unsigned fdw_mul, fdw_shift, fdh_mul, fdh_shift;
     // Winograd F(2x2,3x3) form of a 3x3 / stride 1 / pad 1 layer (kernels_wino.hip); null = not packed
     const float* wino_w;       // [Cin/8][16][wino_n16][128]
     int wino_n16;              // ceil(N / 16)

@@ -372,7 +372,16 @@ static int find_div_mul(int d, int limit) {
     return (int)mul;
 }
 
+static void make_fast_div(unsigned d, unsigned& mul, unsigned& shift) {
+    unsigned l = 0;
+    while ((1u << l) < d) ++l;
+    mul = (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << l) - d)) / d + 1);
+    shift = l;
+}
+
 int conv_igemm_prepare(ConvParams& p) {
+    make_fast_div((unsigned)std::max(p.W, 1), p.fdw_mul, p.fdw_shift);
+    make_fast_div((unsigned)std::max(p.H, 1), p.fdh_mul, p.fdh_shift);
     const int taps = p.KH * p.KW;
     const int limit = p.Kpad / 8 + 8;
     p.taps4 = 4 * taps;
