@@ -36,7 +36,10 @@ template <> struct Mfma<16> {
     static __device__ __forceinline__ int row(int r, int lane) { return (lane >> 4) * 4 + r; }
 };
 
-template <int BM, int BN, int WGM, int WGN, int MT, bool GATE>
+// NS = LDS stages: 2 (next tile stored while the current one is multiplied, one barrier per K tile) or 1 (half the
+// LDS, two barriers per K tile: for the 1-3 tile deep encoder / deconv layers, which are bound by how many workgroups
+// a CU can keep in flight, not by the K loop)
+template <int BM, int BN, int WGM, int WGN, int MT, bool GATE, int NS = 2>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][BM][LDK]
-    float* Bs = smem + 2 * BM * LDK;   // [2][BN][LDK]
+    float* Bs = smem + NS * BM * LDK;  // [NS][BN][LDK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int k_lane = (lane / MT) * 4;
 
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int stage = (kt - kt0) & 1;
+        const int stage = NS == 2 ? (kt - kt0) & 1 : 0;
         // unconditional prefetch keeps the loop free of branches (and the staging registers out of scratch); in the
         // last iteration the activation loads are pointed out of range (zero fill, no memory traffic) - for the
         // 1-3 tile deep encoder layers a real re-read of the tile was 33-100 % extra L2 traffic
@@ -192,7 +195,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
         // ... and the LDS stores (which wait for those loads) BELOW it
         __builtin_amdgcn_sched_barrier(0);
-        CCVPE_STORE_TILE(stage ^ 1);
+        if (NS == 1) __syncthreads();   // single stage: every wave is done reading before the tile is replaced
+        CCVPE_STORE_TILE(NS == 2 ? stage ^ 1 : 0);
         __syncthreads();
     }
 #undef CCVPE_LOAD_TILE
@@ -265,11 +269,11 @@ void launch_splitk_reduce(const ConvParams& p, hipStream_t s) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
 }
 
-template <int BM, int BN, int WGM, int WGN, int MT, bool GATE>
+template <int BM, int BN, int WGM, int WGN, int MT, bool GATE, int NS>
 static void launch_cfg2(const ConvParams& p, hipStream_t s) {
-    constexpr size_t lds = 2 * (BM + BN) * LDK * sizeof(float);
+    constexpr size_t lds = std::max<size_t>(NS * (BM + BN) * LDK, BM * (BN + 4)) * sizeof(float);   // stages | epilogue C tile
     static bool attr_done = false;
-    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, MT, GATE>;
+    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, MT, GATE, NS>;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
@@ -279,10 +283,10 @@ static void launch_cfg2(const ConvParams& p, hipStream_t s) {
     if (p.splitk > 1) launch_splitk_reduce(p, s);
 }
 
-template <int BM, int BN, int WGM, int WGN, int MT>
+template <int BM, int BN, int WGM, int WGN, int MT, int NS = 2>
 static void launch_cfg(const ConvParams& p, hipStream_t s) {
-    if (p.gate) launch_cfg2<BM, BN, WGM, WGN, MT, true>(p, s);
-    else launch_cfg2<BM, BN, WGM, WGN, MT, false>(p, s);
+    if (p.gate) launch_cfg2<BM, BN, WGM, WGN, MT, true, NS>(p, s);
+    else launch_cfg2<BM, BN, WGM, WGN, MT, false, NS>(p, s);
 }
 
 // Tile table.  id = index + 1 (0 is TILE_AUTO).  `intrinsic` is only the prior used when the plan has not been
@@ -307,6 +311,13 @@ static const TileCfg TILES[] = {
     {64, 32, 0.70, "conv_igemm_64x32_m16", launch_cfg<64, 32, 2, 2, 16>},
     {256, 48, 0.85, "conv_igemm_256x48_m16", launch_cfg<256, 48, 4, 1, 16>},
     {64, 128, 0.90, "conv_igemm_64x128_m16", launch_cfg<64, 128, 2, 2, 16>},
+    // single-stage forms of the tiles the shallow layers use (prior 0: only the autotuner picks them)
+    {64, 64, 0.0, "conv_igemm_64x64_m16_s1", launch_cfg<64, 64, 2, 2, 16, 1>},
+    {64, 32, 0.0, "conv_igemm_64x32_m16_s1", launch_cfg<64, 32, 2, 2, 16, 1>},
+    {64, 64, 0.0, "conv_igemm_64x64_m32_s1", launch_cfg<64, 64, 2, 2, 32, 1>},
+    {128, 48, 0.0, "conv_igemm_128x48_m16_s1", launch_cfg<128, 48, 4, 1, 16, 1>},
+    {128, 16, 0.0, "conv_igemm_128x16_m16_s1", launch_cfg<128, 16, 4, 1, 16, 1>},
+    {128, 80, 0.0, "conv_igemm_128x80_m16_s1", launch_cfg<128, 80, 4, 1, 16, 1>},
 };
 static constexpr int NTILES = (int)(sizeof(TILES) / sizeof(TILES[0]));
 
