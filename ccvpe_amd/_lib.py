@@ -47,6 +47,7 @@ SYMBOLS = [
     ("ccvpe_preprocess", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                    C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.c_void_p, C.c_void_p]),
     ("ccvpe_set_debug", C.c_int, [C.c_void_p, C.c_int32]),
+    ("ccvpe_set_streams", C.c_int, [C.c_void_p, C.c_int32]),
     ("ccvpe_read_tap", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                  C.POINTER(C.c_int32 * 4)]),
     ("ccvpe_profile_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,

@@ -151,6 +151,8 @@ class _CVMBase(nn.Module):
             self._rolls = tuple(lib.ccvpe_output_channels(h, k) for k in range(6))
             if self._debug:
                 _lib.check(lib.ccvpe_set_debug(h, 1), "ccvpe_set_debug")
+            if getattr(self, "_n_streams", 2) != 2:
+                _lib.check(lib.ccvpe_set_streams(h, self._n_streams), "ccvpe_set_streams")
         if self._weights_dirty:
             for key, t in self.state_dict().items():
                 if t.dtype != torch.float32 or "._fc." in key:
@@ -259,6 +261,12 @@ class _CVMBase(nn.Module):
         _lib.check(rc, "ccvpe_postprocess")
         f = buf.view(torch.float32)
         return {"index": buf[:, 0].to(torch.int64), "prob": f[:, 1], "cos": f[:, 2], "sin": f[:, 3], "angle_deg": f[:, 4]}
+
+    def set_streams(self, n: int) -> None:
+        """Issue order of later forwards: 2 (default) two-stream schedule, 1 program order (bit-identical results)."""
+        self._n_streams = int(n)
+        if self._handle is not None:
+            _lib.check(_lib.load().ccvpe_set_streams(self._handle, int(n)), "ccvpe_set_streams")
 
     def set_debug(self, enable: bool) -> None:
         self._debug = bool(enable)

@@ -134,6 +134,10 @@ int ccvpe_preprocess(const uint8_t* hwc, int32_t batch, int32_t H, int32_t W, co
  * copied out by name as NCHW float32 into HOST memory (`capacity` in floats).  Returns the number
  * of floats written via *n_out.  Names: see DESIGN.md (e.g. "sat_block15", "loc_level6"). */
 int ccvpe_set_debug(ccvpe_handle h, int32_t enable);
+/* Issue order of the next forward calls: 2 (default) = the aerial encoder and the orientation decoder run on an internal
+ * second stream; 1 = everything in program order on the caller's stream.  Results are bit-identical (test hook and
+ * diagnostic switch; no reference counterpart). */
+int ccvpe_set_streams(ccvpe_handle h, int32_t n_streams);
 int ccvpe_read_tap(ccvpe_handle h, const char* name, float* host_dst, size_t capacity, size_t* n_out,
                    int32_t shape_out[4]);
 
