@@ -110,11 +110,12 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
         // tile slot XOR 8 for kq >= 2: the 8 tiles x 8 channels a wave scatters then cover all 64 banks once
         g_lds[i] = (tg >> 5) * 4096 + (t >> 4) * 128 + ((k & 3) * 16 + ((t & 15) ^ ((k & 2) << 2))) * 2 + (k >> 2);
     }
-    // weights never touch LDS: the host layout is the B-fragment layout, so a wave reads the 512 bytes of its
-    // (xi, 16-channel slice) with one 8-byte load per lane, straight into the MFMA operand registers
-    const unsigned w_xi_b = (unsigned)p.wino_n16 * 512u;             // bytes between consecutive xi
-    const unsigned w_chunk_b = w_xi_b * 16u;                          // bytes per chunk
-#define CCVPE_WINO_WBASE(nb_) ((nb_) * NW + wave < p.wino_n16 ? (unsigned)((nb_) * NW + wave) * 512u + (unsigned)lane * 8u : OOB)
+    // weights never touch LDS: the host layout is the B-fragment layout of two consecutive xi, so a wave reads the
+    // 1024 bytes of its (xi pair, 16-channel slice) with one 16-byte load per lane, straight into the MFMA operand
+    // registers
+    const unsigned w_pair_b = (unsigned)p.wino_n16 * 1024u;          // bytes between consecutive xi pairs
+    const unsigned w_chunk_b = w_pair_b * 8u;                         // bytes per chunk
+#define CCVPE_WINO_WBASE(nb_) ((nb_) * NW + wave < p.wino_n16 ? (unsigned)((nb_) * NW + wave) * 1024u + (unsigned)lane * 16u : OOB)
     unsigned w_base = CCVPE_WINO_WBASE(nb);
 
     // split-K over chunks (blockIdx.z); channel groups of near-equal length, at most GC chunks each
@@ -141,8 +142,12 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
         if (RAW_ITEMS * NT == RAW_F4 || j < RAW_F4)                                                      \
             *reinterpret_cast<f32x4*>(Rs + (j / (2 * GC)) * PXS + (j % (2 * GC)) * 4) = raw[i];          \
     }
-#define CCVPE_WINO_LOAD_B(wb, ch, x)                                                                     \
-    bq[x] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(w_rsrc, wb, (ch) * w_chunk_b + (x) * w_xi_b, 0));
+#define CCVPE_WINO_LOAD_B(wb, ch, g)   /* xi pair g = (2g, 2g+1) */                                      \
+    {                                                                                                    \
+        const f32x4 t4_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wb, (ch) * w_chunk_b + (g) * w_pair_b, 0)); \
+        bq[2 * (g)] = f32x2{t4_.x, t4_.y};                                                               \
+        bq[2 * (g) + 1] = f32x2{t4_.z, t4_.w};                                                           \
+    }
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
 
     CCVPE_WINO_LOAD_RAW(c_begin * 8);
 #pragma unroll
-    for (int x = 0; x < 16; ++x) { CCVPE_WINO_LOAD_B(w_base, c_begin, x); }
+    for (int g = 0; g < 8; ++g) { CCVPE_WINO_LOAD_B(w_base, c_begin, g); }
     CCVPE_WINO_STORE_RAW();
     __syncthreads();
     const float* va0 = Vs + wset * 4096 + ((lane & 48) + ((lane & 15) ^ ((lane & 32) >> 2))) * 2;   // same slot swizzle as g_lds
@@ -267,8 +272,7 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
                     acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][e][1].y, bq[x].y, acc[x][1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                CCVPE_WINO_LOAD_B(wb, chn, g * 2);
-                CCVPE_WINO_LOAD_B(wb, chn, g * 2 + 1);
+                CCVPE_WINO_LOAD_B(wb, chn, g);
             }
 #undef CCVPE_WINO_FRAGS
             __builtin_amdgcn_sched_barrier(0);
@@ -363,7 +367,8 @@ bool conv_wino_supported(const ConvParams& p) {
 }
 
 // Host-side weight transform: U = G g G^T per (cout, cin) in double precision, stored in the LDS image order
-//   [chunk = cin/8][xi][n16][kq = cin%4][nn = cout%16][kh = (cin%8)/4]      (512 B per (xi, n16) = one B-fragment load of a wave)
+//   [chunk = cin/8][xi/2][n16][lane = (cin%4)*16 + cout%16][xi%2][kh = (cin%8)/4]      (1024 B per (xi pair, n16) = one 16-byte
+//   B-fragment load per lane)
 // `get(n, tap, c)` returns the 3x3 weight (tap = ky*3 + kx).
 size_t conv_wino_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out, int* n16_out) {
     static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
@@ -381,7 +386,8 @@ size_t conv_wino_pack(int N, int cin, const std::function<float(int, int, int)>&
             for (int r = 0; r < 4; ++r)
                 for (int q = 0; q < 4; ++q) {
                     const double uv = tmp[r][0] * G[q][0] + tmp[r][1] * G[q][1] + tmp[r][2] * G[q][2];
-                    const size_t idx = ((((size_t)chunk * 16 + (r * 4 + q)) * n16 + n / 16) * 4 + (k & 3)) * 32 + (n % 16) * 2 + (k >> 2);
+                    const int xi = r * 4 + q;
+                    const size_t idx = ((((size_t)chunk * 8 + xi / 2) * n16 + n / 16) * 64 + (k & 3) * 16 + (n % 16)) * 4 + (xi & 1) * 2 + (k >> 2);
                     out[idx] = (float)uv;
                 }
         }
