@@ -322,6 +322,7 @@ struct ccvpe_handle_s {
     hipStream_t aux_stream = nullptr;   // second stream of two-stream plans
     bool two_streams = true;      // CCVPE_STREAMS=1 issues everything on the caller's stream
     bool serial_issue = false;    // ccvpe_set_streams(h, 1): run two-stream plans in program order on one stream
+    bool force_streams = false;   // CCVPE_STREAMS=3 (diagnostic): two streams also in bf16x3 mode
     std::vector<void*> dev_allocs;
     EncoderW grd_enc, sat_enc;
     PackedConv grd_heads, sat_desc;
@@ -751,7 +752,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
     pl.scratch = pl.alloc(1, 1, 1, (int)Plan::SPLITK_FLOATS);
     // (bf16x3 mode stays single-stream: with the second stream an intermittent mismatch of the LDS-DMA staged decoder
     //  layers was seen on one box and not root-caused; the exact-fp32 path is covered by a bitwise two- vs one-stream test)
-    pl.two_streams = h->two_streams && !h->debug && h->cfg.reserved[0] != 1;
+    pl.two_streams = h->two_streams && !h->debug && (h->cfg.reserved[0] != 1 || h->force_streams);
     if (pl.two_streams) pl.scratch2 = pl.alloc(1, 1, 1, (int)Plan::SPLITK_FLOATS);
     pl.use_graph = !cached && (h->graph_mode == 1 || (h->graph_mode < 0 && B <= 4));
     if (pl.use_graph) {
@@ -1083,7 +1084,7 @@ int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
     if (const char* e = getenv("CCVPE_GRAPH")) h->graph_mode = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_FUSE_L1")) h->fuse_level1 = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_WINOGRAD")) h->wino = std::atoi(e) != 0;
-    if (const char* e = getenv("CCVPE_STREAMS")) h->two_streams = std::atoi(e) >= 2;
+    if (const char* e = getenv("CCVPE_STREAMS")) { h->two_streams = std::atoi(e) >= 2; h->force_streams = std::atoi(e) >= 3; }
     if (const char* e = getenv("CCVPE_FUSE_MBCONV")) h->fuse_mbconv = std::atoi(e);
     if (const char* e = getenv("CCVPE_PRECISION")) h->cfg.reserved[0] = (std::string(e) == "bf16x3") ? 1 : 0;
     if (h->cfg.reserved[0] != 0 && h->cfg.reserved[0] != 1) { delete h; return fail(CCVPE_EINVAL, "unknown precision mode %d", cfg->reserved[0]); }
