@@ -789,7 +789,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
         ori_cat[j] = pl.alloc(B, hw_in * 2, hw_in * 2, vs.ori[j].dout + vs.ori[j].skip);
         // bf16x3 mode: tensors consumed only by convolutions live as pre-split bf16 planes (same bytes), so the
         // consumers' K loops carry no fp32->bf16 conversion; level 1 (j == 5) feeds the fp32 tail and stays fp32
-        if (h->cfg.reserved[0] == 1 && j < 5) { loc_cat[j].split = true; ori_cat[j].split = true; }
+        if (h->cfg.reserved[0] == 1 && j < 5 && !getenv("CCVPE_NO_SPLIT_PLANES")) { loc_cat[j].split = true; ori_cat[j].split = true; }
     }
     ori_in6 = pl.alloc(B, 8, 8, rpad + D);
 
@@ -1213,7 +1213,9 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
         const int nkt = op.gemm_kpad / 32;
         for (int t = 1; t <= nt; ++t) {
             if (conv_igemm_tile_util(q, t) < 0.45) continue;
-            if (conv_igemm_tile_is_bf16x3(t) && h->cfg.reserved[0] != 1) continue;
+            if (conv_igemm_tile_is_bf16x3(t) && (h->cfg.reserved[0] != 1 || getenv("CCVPE_TUNE_NO_BF16X3"))) continue;
+            if (const char* only = getenv("CCVPE_TUNE_BF16_ONLY"))   // diagnostic: keep only bf16x3 tiles whose name contains the string
+                if (conv_igemm_tile_is_bf16x3(t) && !std::strstr(conv_igemm_tile_name(t), only)) continue;
             if (op.bf16x3_only && !conv_igemm_tile_is_bf16x3(t)) continue;
             if (conv_igemm_tile_is_wino(t) && !op.wino_ok) continue;
             const long long blocks = conv_igemm_tile_blocks(q, t);
