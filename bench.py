@@ -179,7 +179,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": args.workload + ("+cached_aerial" if args.cached_aerial else ""), "variant": variant, "batch_per_gpu": args.batch,
                    "global_batch": world * args.batch, "grd": list(grd.shape[1:]), "sat": list(sat.shape[1:]),
-                   "parallelism": f"image-parallel x{world}, all_gather of 20 B/query results"},
+                   "parallelism": f"image-parallel x{world}, all_gather of 20 B/query results",
+                   "schedule": "single stream" if os.environ.get("CCVPE_STREAMS") == "1" or args.precision != "fp32" else "two streams per GPU (aerial encoder + orientation decoder on the second)"},
     }
 
     if rank == 0:

@@ -10,7 +10,16 @@ import torch.nn.functional as F
 from ccvpe_amd import _lib
 
 _l = _lib.load()
+import re
+
 TILES = {t: _l.ccvpe_op_tile_name(t).decode().replace("conv_igemm_", "") for t in range(1, _l.ccvpe_op_num_tiles() + 1)}
+
+
+def tile_dims(name):
+    """(rows, cols) of a tile from its name; Winograd tiles are named <2x2 tiles>x<channels> (4 output pixels per tile)."""
+    m = re.search(r"(\d+)x(\d+)", name)
+    bm, bn = int(m.group(1)), int(m.group(2))
+    return (bm * 4 if "wino" in name else bm), bn
 
 # (name, B, H, W, Cin, Cout, K)
 SHAPES = [
@@ -45,7 +54,9 @@ def main():
         line = f"{name:12s} M={B*H*W:8d} N={Cout:5d} K={Cin*K*K:6d} |"
         M_, N_ = B * H * W, Cout
         for tid, tn in TILES.items():
-            bm, bn = [int(v) for v in tn.split("_")[0].split("x")]
+            bm, bn = tile_dims(tn)
+            if "wino" in tn and (K != 3 or H % 16 or W % 16):
+                continue
             util = (M_ * N_) / (-(-M_ // bm) * bm * -(-N_ // bn) * bn)
             if util < 0.45:
                 continue
