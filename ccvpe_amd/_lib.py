@@ -35,25 +35,32 @@ SYMBOLS = [
     ("ccvpe_set_weight", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     ("ccvpe_skip_weight", C.c_int, [C.c_void_p, C.c_char_p]),
     ("ccvpe_finalize_weights", C.c_int, [C.c_void_p]),
+    ("ccvpe_max_micro_batch", C.c_int, [C.c_int32, C.c_float, C.c_int32, C.c_int32]),
     ("ccvpe_output_channels", C.c_int, [C.c_void_p, C.c_int32]),
     ("ccvpe_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     ("ccvpe_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                 C.POINTER(Outputs), C.c_void_p]),
     ("ccvpe_postprocess", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("ccvpe_eval_metrics", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
     ("ccvpe_aerial_cache_bytes", C.c_size_t, [C.c_void_p, C.c_int32]),
     ("ccvpe_encode_aerial", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     ("ccvpe_forward_cached", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                        C.POINTER(Outputs), C.c_void_p]),
     ("ccvpe_preprocess", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                    C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.c_void_p, C.c_void_p]),
+    ("ccvpe_preprocess_resize", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                          C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ccvpe_set_debug", C.c_int, [C.c_void_p, C.c_int32]),
     ("ccvpe_set_streams", C.c_int, [C.c_void_p, C.c_int32]),
     ("ccvpe_read_tap", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                  C.POINTER(C.c_int32 * 4)]),
+    ("ccvpe_debug_dump_plan", C.c_int, [C.c_void_p, C.c_char_p]),
     ("ccvpe_profile_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                         C.POINTER(Outputs), C.c_void_p]),
     ("ccvpe_profile_row", C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_float),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("ccvpe_profile_row_issued", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     ("ccvpe_op_num_tiles", C.c_int, []),
     ("ccvpe_op_tile_name", C.c_char_p, [C.c_int32]),
     ("ccvpe_op_conv2d", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
@@ -88,6 +95,32 @@ def preprocess(img_u8_hwc, shift=None, crop_w=None, mean=IMAGENET_MEAN, std=IMAG
     return out
 
 
+def preprocess_resize(img_u8_hwc, out_hw, shift=None, crop_w=None, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """uint8 [B,H,W,3] cuda tensor as decoded -> PIL-exact bilinear resize to out_hw -> float32 NCHW [B,3,OH,crop_w]
+    (transforms.Resize + ToTensor + Normalize + roll + FoV crop, train_VIGOR.py:57-70, datasets.py:118, train_VIGOR.py:272-273)."""
+    import torch
+    lib = load()
+    assert img_u8_hwc.is_cuda and img_u8_hwc.dtype == torch.uint8 and img_u8_hwc.dim() == 4 and img_u8_hwc.shape[3] == 3
+    img = img_u8_hwc.contiguous()
+    B, H, W, _ = img.shape
+    OH, OW = int(out_hw[0]), int(out_hw[1])
+    crop_w = OW if crop_w is None else int(crop_w)
+    out = torch.empty((B, 3, OH, crop_w), dtype=torch.float32, device=img.device)
+    scratch = torch.empty((B, H, OW, 3), dtype=torch.uint8, device=img.device) if W != OW else None
+    sh = None
+    if shift is not None:
+        sh = torch.as_tensor(shift, dtype=torch.int32, device=img.device).contiguous()
+        assert sh.numel() == B
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    stream = torch.cuda.current_stream(img.device).cuda_stream
+    rc = lib.ccvpe_preprocess_resize(C.c_void_p(img.data_ptr()), B, H, W, OH, OW, C.c_void_p(sh.data_ptr()) if sh is not None else None,
+                                     crop_w, C.byref(m), C.byref(s), C.c_void_p(scratch.data_ptr()) if scratch is not None else None,
+                                     C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+    check(rc, "ccvpe_preprocess_resize")
+    return out
+
+
 def op_conv2d(x_nhwc, w, bias=None, stride=1, pad=0, act=0, tile=0, iters=0):
     """Kernel-level hook: x [B,H,W,Cin] cuda fp32, w [Cout,Cin,KH,KW], returns (out NHWC, mean ms or None)."""
     import torch
@@ -116,6 +149,15 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    override = os.environ.get("CCVPE_LIB_PATH")   # diagnostics: load an alternative build of the same ABI
+    if override:
+        lib = C.CDLL(override)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
     try:   # rebuild when the sources are newer than the library (hipcc cross-compiles in seconds)
         from . import build as _build
         if not _build.is_current():

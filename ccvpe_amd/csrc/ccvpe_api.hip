@@ -177,6 +177,7 @@ struct Op {
     // implicit-GEMM launches: tile id the launch uses (0 = heuristic) - set by Plan::autotune
     std::shared_ptr<int> tile;
     int gemm_m = 0, gemm_n = 0, gemm_kpad = 0;
+    int conv_cin = 0;             // 3x3 layers: input channels (issued-FLOP accounting of the Winograd tiles)
     bool bf16x3_only = false;     // the launch reads a pre-split bf16 tensor: exact-fp32 tiles cannot serve it
     bool wino_ok = false;         // 3x3 / stride 1 layer with Winograd-domain weights packed
     // two-stream execution (Plan::schedule): stream the op is issued on, ops of the other stream it must wait for,
@@ -246,9 +247,17 @@ struct Plan {
     }
     static constexpr size_t SPLITK_FLOATS = 32u << 20;   // 128 MiB: 16 slabs of M*N <= 2M outputs
 
+    // every kernel addresses a tensor with 32-bit byte offsets (raw buffer loads, `unsigned in_bytes`, the 0x80000000
+    // out-of-range sentinel): no tensor of a plan may reach 2 GiB - checked at the end of build_plan
+    size_t max_tensor_bytes = 0;
+    int max_dims[4] = {0, 0, 0, 0};
     Tensor alloc(int B_, int H, int W, int C) {
         Tensor t; t.id = (int)size.size(); t.B = B_; t.H = H; t.W = W; t.C = C;
         size.push_back((size_t)B_ * H * W * C);
+        if (size.back() * sizeof(float) > max_tensor_bytes) {
+            max_tensor_bytes = size.back() * sizeof(float);
+            max_dims[0] = B_; max_dims[1] = H; max_dims[2] = W; max_dims[3] = C;
+        }
         return t;
     }
     void add(const std::string& name, std::vector<Tensor> uses, std::function<void(const Ctx&)> fn, double flops = 0, double bytes = 0) {
@@ -265,41 +274,59 @@ struct Plan {
         ops.back().gemm_n = gemm_n;
         ops.back().gemm_kpad = gemm_kpad;
     }
+    // Workspace layout.  Single-stream plans: first-fit with lifetime reuse over the program order.  Two-stream plans:
+    // memory may only be recycled between tensors whose launches are ordered whichever way the plan is issued - i.e.
+    // tensors touched by ONE stream only, recycled among tensors of the same stream (stream order == program order).
+    // Tensors that both streams touch (the concat buffers the aerial encoder's taps land in, the descriptor map, the
+    // level-1 score stack) keep private memory for the whole plan, so a recycled address never adds a dependency the
+    // event edges do not know about.  Three regions: [stream-0 pool | stream-1 pool | cross-stream and pinned tensors].
     void assign() {
         const int n = (int)size.size();
-        std::vector<int> first(n, 1 << 30), last(n, -1);
+        std::vector<int> first(n, 1 << 30), last(n, -1), smask(n, 0);
         for (int i = 0; i < (int)ops.size(); ++i)
-            for (int id : ops[i].uses) { first[id] = std::min(first[id], i); last[id] = std::max(last[id], i); }
-        if (debug || two_streams) for (int i = 0; i < n; ++i) last[i] = 1 << 30;
-        if (scratch.id >= 0) { first[scratch.id] = 0; last[scratch.id] = 1 << 30; }
-        if (scratch2.id >= 0) { first[scratch2.id] = 0; last[scratch2.id] = 1 << 30; }
-        if (tune_cache.id >= 0) { first[tune_cache.id] = 0; last[tune_cache.id] = 1 << 30; }
-        if (use_graph)
-            for (const Tensor* t : {&io_grd, &io_sat, &io_logits, &io_heat, &io_ori, &io_ms[0], &io_ms[1], &io_ms[2], &io_ms[3], &io_ms[4], &io_ms[5]}) {
-                first[t->id] = 0; last[t->id] = 1 << 30;
+            for (int id : ops[i].uses) {
+                first[id] = std::min(first[id], i); last[id] = std::max(last[id], i);
+                smask[id] |= 1 << (two_streams ? ops[i].stream : 0);
             }
+        static const bool no_reuse = getenv("CCVPE_NO_REUSE") != nullptr;   // diagnostic: every tensor keeps its memory
+        std::vector<bool> pinned(n, false);
+        auto pin = [&](const Tensor& t) { if (t.id >= 0) { pinned[t.id] = true; first[t.id] = 0; last[t.id] = 1 << 30; } };
+        if (debug || no_reuse) for (int i = 0; i < n; ++i) if (last[i] >= 0) pinned[i] = true;
+        pin(scratch); pin(scratch2); pin(tune_cache);
+        if (use_graph)
+            for (const Tensor* t : {&io_grd, &io_sat, &io_logits, &io_heat, &io_ori, &io_ms[0], &io_ms[1], &io_ms[2], &io_ms[3], &io_ms[4], &io_ms[5]}) pin(*t);
+        for (int i = 0; i < n; ++i) if (smask[i] == 3) pinned[i] = true;
         off.assign(n, 0);
         std::vector<int> order(n);
         for (int i = 0; i < n; ++i) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
-        std::vector<int> placed;
+        auto granule = [&](int id) { return (size[id] + 63) & ~(size_t)63; };   // 256-byte granules
         total = 0;
-        for (int id : order) {
-            if (last[id] < 0) continue;   // never used
-            const size_t sz = (size[id] + 63) & ~(size_t)63;   // 256-byte granules
-            // candidate offsets: 0 and the end of every live, lifetime-overlapping tensor
-            std::vector<std::pair<size_t, size_t>> busy;
-            for (int o : placed)
-                if (!(last[o] < first[id] || last[id] < first[o])) busy.push_back({off[o], off[o] + ((size[o] + 63) & ~(size_t)63)});
-            std::sort(busy.begin(), busy.end());
-            size_t pos = 0;
-            for (auto& iv : busy) {
-                if (pos + sz <= iv.first) break;
-                pos = std::max(pos, iv.second);
+        for (int pool = 1; pool <= 2; ++pool) {   // recycled regions of stream 0 and stream 1
+            const size_t base = total;
+            std::vector<int> placed;
+            for (int id : order) {
+                if (last[id] < 0 || pinned[id] || smask[id] != pool) continue;
+                const size_t sz = granule(id);
+                // candidate offsets: the region start and the end of every live, lifetime-overlapping tensor
+                std::vector<std::pair<size_t, size_t>> busy;
+                for (int o : placed)
+                    if (!(last[o] < first[id] || last[id] < first[o])) busy.push_back({off[o], off[o] + granule(o)});
+                std::sort(busy.begin(), busy.end());
+                size_t pos = base;
+                for (auto& iv : busy) {
+                    if (pos + sz <= iv.first) break;
+                    pos = std::max(pos, iv.second);
+                }
+                off[id] = pos;
+                total = std::max(total, pos + sz);
+                placed.push_back(id);
             }
-            off[id] = pos;
-            total = std::max(total, pos + sz);
-            placed.push_back(id);
+        }
+        for (int id : order) {   // private memory
+            if (last[id] < 0 || !pinned[id]) continue;
+            off[id] = total;
+            total += granule(id);
         }
     }
 };
@@ -316,13 +343,15 @@ struct ccvpe_handle_s {
     bool autotune = true;
     int fuse_mbconv = 1;          // CCVPE_FUSE_MBCONV: 0 never, 1 where measured profitable (3x3 blocks), 2 every supported block
     bool fuse_level1 = true;      // CCVPE_FUSE_L1=0 falls back to deconv / conv / tail launches
-    bool wino = true;             // CCVPE_WINOGRAD=0 keeps the decoder 3x3 layers on the implicit GEMM
+    // CCVPE_WINOGRAD=0 keeps the decoder 3x3 layers on the implicit GEMM.  fp32 plans only: conv_wino_kernel's column pass
+    // is a v_pk_add_f32 with op_sel:[0,1], which gfx950 mis-executes beside another wave's bf16 MFMAs, so a
+    // bf16x3 plan never contains it
+    bool wino = true;
     int graph_mode = -1;          // -1 auto (plans of <= 4 samples replay a hipGraph), 0 never, 1 always
     hipStream_t capture_stream = nullptr;
     hipStream_t aux_stream = nullptr;   // second stream of two-stream plans
     bool two_streams = true;      // CCVPE_STREAMS=1 issues everything on the caller's stream
     bool serial_issue = false;    // ccvpe_set_streams(h, 1): run two-stream plans in program order on one stream
-    bool force_streams = false;   // CCVPE_STREAMS=3 (diagnostic): two streams also in bf16x3 mode
     std::vector<void*> dev_allocs;
     EncoderW grd_enc, sat_enc;
     PackedConv grd_heads, sat_desc;
@@ -330,10 +359,18 @@ struct ccvpe_handle_s {
     float grd_b2[6] = {0};
     DecoderW loc, ori;
     std::vector<std::unique_ptr<Plan>> plans;
+    Plan* last_plan = nullptr;    // plan of the most recent forward (ccvpe_debug_dump_plan)
+    // diagnostics (environment, read at ccvpe_create): CCVPE_DIAG_SYNC_BEFORE=<name part> drains the device before matching
+    // launches; CCVPE_DIAG_SNAP=<launch name> copies that launch's tensors aside (stream ordered) right before and right after it
+    std::string diag_sync, diag_snap;
+    float* snap[2] = {nullptr, nullptr};
+    size_t snap_floats = 0;
+    std::vector<std::pair<int, size_t>> snap_layout;   // (tensor id, float offset inside a snapshot buffer)
+    std::map<std::pair<int, int>, int> mb_cap;   // ground size -> ccvpe_max_micro_batch (2 GiB tensor bound)
     float* arena = nullptr;
     size_t arena_floats = 0;
     // profiling rows of the last ccvpe_profile_forward
-    struct Row { std::string name; float ms; double flops, bytes; };
+    struct Row { std::string name; float ms; double flops, bytes, issued; };
     std::vector<Row> prof;
 };
 
@@ -742,6 +779,7 @@ static size_t cache_layout(const VariantSpec& vs, int B, size_t off[6]) {
 }
 
 static int build_aerial_plan(ccvpe_handle_s* h, Plan& pl, int B);
+extern "C" int ccvpe_max_micro_batch(int32_t variant, float ori_noise, int32_t grd_h, int32_t grd_w);
 
 static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode = 0) {
     if (mode == 1) return build_aerial_plan(h, pl, B);
@@ -750,9 +788,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
     const VariantSpec& vs = h->vs;
     pl.B = B; pl.gh = gh; pl.gw = gw; pl.debug = h->debug;
     pl.scratch = pl.alloc(1, 1, 1, (int)Plan::SPLITK_FLOATS);
-    // (bf16x3 mode stays single-stream: with the second stream an intermittent mismatch of the LDS-DMA staged decoder
-    //  layers was seen on one box and not root-caused; the exact-fp32 path is covered by a bitwise two- vs one-stream test)
-    pl.two_streams = h->two_streams && !h->debug && (h->cfg.reserved[0] != 1 || h->force_streams);
+    pl.two_streams = h->two_streams && !h->debug;
     if (pl.two_streams) pl.scratch2 = pl.alloc(1, 1, 1, (int)Plan::SPLITK_FLOATS);
     pl.use_graph = !cached && (h->graph_mode == 1 || (h->graph_mode < 0 && B <= 4));
     if (pl.use_graph) {
@@ -887,7 +923,8 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
                 c.launch_conv(p, tile);
             }, 2.0 * B * hout * hout * 9.0 * cat.C * l.mid, 4.0 * B * hout * hout * ((double)cat.C + l.mid));
             pl.ops.back().bf16x3_only = cat.split;
-            pl.ops.back().wino_ok = pc->wino != nullptr && !cat.split && h->wino;
+            pl.ops.back().conv_cin = cat.C;
+            pl.ops.back().wino_ok = pc->wino != nullptr && !cat.split && h->wino && h->cfg.reserved[0] == 0;
         }
         if (j == 5) return mid;   // tail conv handled by the caller
         Tensor o = pl.alloc(B, hout, hout, l.out);
@@ -900,7 +937,8 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
                 c.launch_conv(p, tile);
             }, 2.0 * B * hout * hout * 9.0 * l.mid * l.out, 4.0 * B * hout * hout * ((double)l.mid + l.out));
             pl.ops.back().bf16x3_only = mid.split;
-            pl.ops.back().wino_ok = pc->wino != nullptr && !mid.split && h->wino;
+            pl.ops.back().conv_cin = mid.C;
+            pl.ops.back().wino_ok = pc->wino != nullptr && !mid.split && h->wino && h->cfg.reserved[0] == 0;
         }
         return o;
     };
@@ -1019,6 +1057,11 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
         }, 2.0 * B * 262144.0 * 288, 4.0 * B * 262144.0 * 18);
         }
     }
+    // the ground / aerial inputs and the 2 x 512 x 512 orientation output are addressed the same way
+    pl.max_tensor_bytes = std::max(pl.max_tensor_bytes, (size_t)B * 3 * std::max(gh * gw, CCVPE_SAT_HW * CCVPE_SAT_HW) * sizeof(float));
+    if (pl.max_tensor_bytes >= ((size_t)1 << 31))
+        return fail(CCVPE_EINVAL, "micro-batch %d needs a %d x %d x %d x %d tensor of %zu bytes; the kernels address tensors with 32-bit byte offsets (< 2 GiB): "
+                    "use a smaller micro_batch (ccvpe_max_micro_batch)", B, pl.max_dims[0], pl.max_dims[1], pl.max_dims[2], pl.max_dims[3], pl.max_tensor_bytes);
     pl.schedule();
     pl.assign();
     return 0;
@@ -1056,6 +1099,15 @@ static int build_aerial_plan(ccvpe_handle_s* h, Plan& pl, int B) {
 }
 
 
+
+// Integer checksum of a tensor's bytes (diagnostics: ccvpe_debug_dump_plan)
+__global__ __launch_bounds__(256) void checksum_kernel(const uint32_t* __restrict__ p, size_t n, unsigned long long* out) {
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += (unsigned long long)p[i] * (unsigned long long)((i & 1023) + 1);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -1084,8 +1136,10 @@ int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
     if (const char* e = getenv("CCVPE_GRAPH")) h->graph_mode = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_FUSE_L1")) h->fuse_level1 = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_WINOGRAD")) h->wino = std::atoi(e) != 0;
-    if (const char* e = getenv("CCVPE_STREAMS")) { h->two_streams = std::atoi(e) >= 2; h->force_streams = std::atoi(e) >= 3; }
+    if (const char* e = getenv("CCVPE_STREAMS")) h->two_streams = std::atoi(e) >= 2;
     if (const char* e = getenv("CCVPE_FUSE_MBCONV")) h->fuse_mbconv = std::atoi(e);
+    if (const char* e = getenv("CCVPE_DIAG_SYNC_BEFORE")) h->diag_sync = e;
+    if (const char* e = getenv("CCVPE_DIAG_SNAP")) h->diag_snap = e;
     if (const char* e = getenv("CCVPE_PRECISION")) h->cfg.reserved[0] = (std::string(e) == "bf16x3") ? 1 : 0;
     if (h->cfg.reserved[0] != 0 && h->cfg.reserved[0] != 1) { delete h; return fail(CCVPE_EINVAL, "unknown precision mode %d", cfg->reserved[0]); }
     const int n = (int)(cfg->ori_noise / 18.f);
@@ -1100,12 +1154,33 @@ int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
     return 0;
 }
 
+int ccvpe_max_micro_batch(int32_t variant, float ori_noise, int32_t grd_h, int32_t grd_w) {
+    if (variant < 0 || variant > 3) return fail(CCVPE_EINVAL, "unknown variant %d", variant);
+    // a device-less stand-in handle: build_plan only sizes tensors and records launches, it never touches HIP.
+    // fuse_mbconv = 0 sizes the unfused (largest) form of every MBConv block, so the bound holds for every plan.
+    ccvpe_handle_s tmp;
+    tmp.cfg.variant = variant; tmp.cfg.ori_noise = ori_noise; tmp.cfg.micro_batch = 1;
+    tmp.vs = make_variant(variant);
+    tmp.fuse_mbconv = 0; tmp.two_streams = false; tmp.graph_mode = 0;
+    const int n = (int)(ori_noise / 18.f);
+    for (int k = 0; k < 6; ++k) tmp.rolls[k] = (variant == CCVPE_VARIANT_VIGOR_ORI_PRIOR && k > 0) ? 2 * n + 1 : tmp.vs.n_rolls;
+    int lo = 0, hi = 1024;   // invariant: lo fits (0 = nothing fits / bad geometry), hi does not
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) / 2;
+        Plan pl;
+        if (build_plan(&tmp, pl, mid, grd_h, grd_w) == 0) lo = mid; else hi = mid;
+    }
+    if (lo == 0) return fail(CCVPE_EINVAL, "ground size %d x %d is not valid for variant %d: %s", grd_h, grd_w, variant, g_err.c_str());
+    return lo;
+}
+
 int ccvpe_destroy(ccvpe_handle h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->arena) (void)hipFree(h->arena);
     h->plans.clear();
+    for (int k = 0; k < 2; ++k) if (h->snap[k]) (void)hipFree(h->snap[k]);
     if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     delete h;
@@ -1150,6 +1225,7 @@ int ccvpe_finalize_weights(ccvpe_handle h) {
     for (void* p : h->dev_allocs) (void)hipFree(p);
     h->dev_allocs.clear();
     h->plans.clear();
+    h->last_plan = nullptr;
     int rc;
     if ((rc = build_encoder(h, h->grd_enc, "grd_efficientnet"))) return rc;
     if ((rc = build_encoder(h, h->sat_enc, "sat_efficientnet"))) return rc;
@@ -1316,7 +1392,23 @@ static int run_ops(ccvpe_handle h, Plan& pl, const Ctx& base, hipStream_t s0) {
     for (size_t i = 0; i < n; ++i) {
         Op& op = pl.ops[i];
         for (int d : op.wait_on) HIPCHK(hipStreamWaitEvent(st[op.stream], pl.events[d], 0));
+        if (!h->diag_sync.empty() && op.name.find(h->diag_sync) != std::string::npos) HIPCHK(hipDeviceSynchronize());
+        const bool snap = !h->diag_snap.empty() && op.name == h->diag_snap;
+        auto take_snap = [&](int which) -> int {
+            if (!h->snap[0]) {
+                h->snap_layout.clear();
+                size_t o = 0;
+                for (int id : op.uses) { h->snap_layout.push_back({id, o}); o += (pl.size[id] + 63) & ~(size_t)63; }
+                h->snap_floats = o;
+                for (int k = 0; k < 2; ++k) HIPCHK(hipMalloc((void**)&h->snap[k], o * sizeof(float)));
+            }
+            for (auto& e : h->snap_layout)
+                HIPCHK(hipMemcpyAsync(h->snap[which] + e.second, base.arena + pl.off[e.first], pl.size[e.first] * sizeof(float), hipMemcpyDeviceToDevice, st[op.stream]));
+            return 0;
+        };
+        if (snap) { if (int r = take_snap(0)) return r; }
         op.fn(c[op.stream]);
+        if (snap) { if (int r = take_snap(1)) return r; }
         if (op.signal) HIPCHK(hipEventRecord(pl.events[i], st[op.stream]));
     }
     HIPCHK(hipEventRecord(pl.events[n + 1], st[1]));        // join
@@ -1336,7 +1428,17 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
     for (int k = 0; k < 6; ++k) if (!out->matching_score[k]) return fail(CCVPE_EINVAL, "null matching_score[%d]", k);
     HIPCHK(hipSetDevice(h->cfg.device));
     if (profile) h->prof.clear();
-    const int mbmax = h->cfg.micro_batch;
+    int mbmax = h->cfg.micro_batch;
+    {   // never build a plan with a tensor of 2 GiB or more (32-bit byte offsets): larger batches loop
+        auto it = h->mb_cap.find({gh, gw});
+        if (it == h->mb_cap.end()) {
+            const std::string keep = g_err;
+            const int cap = ccvpe_max_micro_batch(h->cfg.variant, h->cfg.ori_noise, gh, gw);
+            g_err = keep;
+            it = h->mb_cap.emplace(std::make_pair(gh, gw), cap).first;
+        }
+        if (it->second > 0) mbmax = std::min(mbmax, it->second);
+    }
     // make sure every plan (and the largest arena) exists before the first launch
     for (int done = 0; done < batch;) {
         const int mb = std::min(mbmax, batch - done);
@@ -1349,6 +1451,7 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
         const int mb = std::min(mbmax, batch - done);
         Plan* pl; int rc = get_plan(h, mb, gh, gw, &pl, mode);
         if (rc) return rc;
+        h->last_plan = pl;
         Ctx c;
         c.cache_in = cache;
         c.arena = h->arena; c.off = &pl->off; c.stream = stream;
@@ -1412,11 +1515,20 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
                 HIPCHK(hipEventElapsedTime(&ms, e0, e1));
                 const int tile = conv_igemm_last_tile();
                 std::string nm = op.name;
+                double issued = op.flops;   // launches that are not tiled GEMMs: issued == algorithmic
                 if (tile) {
                     nm += std::string("|") + conv_igemm_tile_name(tile);
                     if ((tile >> 8) > 1) nm += "_splitk" + std::to_string(tile >> 8);
+                    // FLOPs the launch puts on the matrix pipe: M and N padded to the tile, K to the packed depth;
+                    // Winograd F(2x2,3x3): 16 products per 2x2 output tile and channel pair; bf16x3: three MFMAs per product
+                    ConvParams q{};
+                    q.M = op.gemm_m; q.N = op.gemm_n;
+                    const double util = conv_igemm_tile_util(q, tile & 0xff);
+                    const double mn_pad = util > 0 ? (double)op.gemm_m * op.gemm_n / util : 0.0;
+                    if (conv_igemm_tile_is_wino(tile)) issued = 2.0 * mn_pad * 4.0 * op.conv_cin;
+                    else issued = 2.0 * mn_pad * op.gemm_kpad * (conv_igemm_tile_is_bf16x3(tile) ? 3.0 : 1.0);
                 }
-                h->prof.push_back({nm, ms, op.flops, op.bytes});
+                h->prof.push_back({nm, ms, op.flops, op.bytes, issued});
             }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
@@ -1451,6 +1563,12 @@ int ccvpe_profile_row(ccvpe_handle h, int32_t i, char* name_buf, size_t name_cap
     return 0;
 }
 
+int ccvpe_profile_row_issued(ccvpe_handle h, int32_t i, double* issued_flops) {
+    if (!h || i < 0 || i >= (int)h->prof.size() || !issued_flops) return fail(CCVPE_EINVAL, "row out of range");
+    *issued_flops = h->prof[i].issued;
+    return 0;
+}
+
 int ccvpe_postprocess(ccvpe_handle h, const float* heatmap, const float* ori, int32_t batch, ccvpe_pose* poses, void* stream) {
     if (!h || !heatmap || !ori || !poses || batch <= 0) return fail(CCVPE_EINVAL, "bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1458,6 +1576,18 @@ int ccvpe_postprocess(ccvpe_handle h, const float* heatmap, const float* ori, in
     launch_postprocess(heatmap, ori, batch, CCVPE_OUT_HW * CCVPE_OUT_HW, reinterpret_cast<PoseOut*>(poses), (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CCVPE_EHIP, "postprocess launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int ccvpe_eval_metrics(ccvpe_handle h, const ccvpe_pose* poses, const float* heatmap, int32_t batch, const int32_t* gt_index,
+                       const float* gt_cos_sin, const double* meter_per_pixel, const double* heading_deg, ccvpe_metrics* out, void* stream) {
+    if (!h || !poses || !heatmap || !gt_index || !meter_per_pixel || !out || batch <= 0) return fail(CCVPE_EINVAL, "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    static_assert(sizeof(ccvpe_metrics) == sizeof(MetricsOut), "metrics layout");
+    launch_metrics(reinterpret_cast<const PoseOut*>(poses), heatmap, batch, CCVPE_OUT_HW, CCVPE_OUT_HW * CCVPE_OUT_HW, gt_index, gt_cos_sin,
+                   meter_per_pixel, heading_deg, reinterpret_cast<MetricsOut*>(out), (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CCVPE_EHIP, "metrics launch failed: %s", hipGetErrorString(e));
     return 0;
 }
 
@@ -1552,6 +1682,75 @@ int ccvpe_preprocess(const uint8_t* hwc, int32_t batch, int32_t H, int32_t W, co
     launch_preprocess(p, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CCVPE_EHIP, "preprocess launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+
+int ccvpe_preprocess_resize(const uint8_t* hwc, int32_t batch, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                            const int32_t* shift, int32_t crop_w, const float mean[3], const float stdv[3], uint8_t* scratch,
+                            float* out_nchw, void* stream) {
+    if (!hwc || !out_nchw || !mean || !stdv) return fail(CCVPE_EINVAL, "null argument");
+    if (batch <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || crop_w <= 0 || crop_w > out_w) return fail(CCVPE_EINVAL, "bad geometry");
+    if (in_w != out_w && !scratch) return fail(CCVPE_EINVAL, "scratch of batch*in_h*out_w*3 bytes is required when the width changes");
+    if ((double)batch * in_h * std::max(in_w, out_w) * 3 >= 2147483647.0 * 2) return fail(CCVPE_EINVAL, "image batch too large");
+    ResizeParams p{};
+    p.in = hwc; p.B = batch; p.IH = in_h; p.IW = in_w; p.OH = out_h; p.OW = out_w; p.crop_w = crop_w; p.tmp = scratch; p.shift = shift; p.out = out_nchw;
+    for (int c = 0; c < 3; ++c) { p.mean[c] = mean[c]; p.stdv[c] = stdv[c]; }
+    if (launch_resize(p, (hipStream_t)stream) != 0) return fail(CCVPE_EINVAL, "down-scaling factors above 8 are not supported (%dx%d -> %dx%d)", in_h, in_w, out_h, out_w);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CCVPE_EHIP, "resize launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int ccvpe_debug_dump_plan(ccvpe_handle h, const char* path) {
+    if (!h || !path) return fail(CCVPE_EINVAL, "null argument");
+    Plan* pl = h->last_plan;
+    if (!pl) return fail(CCVPE_ESTATE, "no forward has run on this handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipDeviceSynchronize());
+    const size_t n = pl->size.size();
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, n * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(d, 0, n * sizeof(unsigned long long)));
+    for (size_t id = 0; id < n; ++id) {
+        if (pl->size[id] == 0) continue;
+        const int blocks = (int)std::min<size_t>((pl->size[id] + 255) / 256, 2048);
+        hipLaunchKernelGGL(checksum_kernel, dim3(blocks), dim3(256), 0, nullptr, reinterpret_cast<const uint32_t*>(h->arena + pl->off[id]), pl->size[id], d + id);
+    }
+    std::vector<unsigned long long> sums(n);
+    hipError_t e = hipMemcpy(sums.data(), d, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(CCVPE_EHIP, "checksum copy failed: %s", hipGetErrorString(e));
+    FILE* f = std::fopen(path, "w");
+    if (!f) return fail(CCVPE_EINVAL, "cannot open %s", path);
+    std::fprintf(f, "# plan B=%d grd=%dx%d mode=%d two_streams=%d tensors=%zu arena_floats=%zu\n", pl->B, pl->gh, pl->gw, pl->mode, (int)pl->two_streams, n, pl->total);
+    for (size_t i = 0; i < pl->ops.size(); ++i) {
+        const Op& op = pl->ops[i];
+        std::fprintf(f, "op %zu %s stream=%d wait=%d signal=%d tile=%s", i, op.name.c_str(), op.stream, op.wait_on.empty() ? -1 : op.wait_on[0], (int)op.signal,
+                     op.tile ? conv_igemm_tile_name(*op.tile & 0xff) : "-");
+        if (op.tile && (*op.tile >> 8) > 1) std::fprintf(f, "_splitk%d", *op.tile >> 8);
+        for (int id : op.uses) std::fprintf(f, " t%d[off=%zu,n=%zu]=%016llx", id, pl->off[id], pl->size[id], sums[id]);
+        std::fprintf(f, "\n");
+    }
+    if (h->snap[0]) {   // CCVPE_DIAG_SNAP: what the named launch's tensors held right before / right after it, in stream order
+        for (int which = 0; which < 2; ++which) {
+            std::fprintf(f, "snap_%s %s", which ? "after" : "before", h->diag_snap.c_str());
+            for (auto& e : h->snap_layout) {
+                unsigned long long* dd = nullptr;
+                unsigned long long v = 0;
+                if (hipMalloc((void**)&dd, sizeof(v)) == hipSuccess) {
+                    (void)hipMemset(dd, 0, sizeof(v));
+                    const int blocks = (int)std::min<size_t>((pl->size[e.first] + 255) / 256, 2048);
+                    hipLaunchKernelGGL(checksum_kernel, dim3(blocks), dim3(256), 0, nullptr, reinterpret_cast<const uint32_t*>(h->snap[which] + e.second), pl->size[e.first], dd);
+                    (void)hipMemcpy(&v, dd, sizeof(v), hipMemcpyDeviceToHost);
+                    (void)hipFree(dd);
+                }
+                std::fprintf(f, " t%d=%016llx", e.first, v);
+            }
+            std::fprintf(f, "\n");
+        }
+    }
+    std::fclose(f);
     return 0;
 }
 

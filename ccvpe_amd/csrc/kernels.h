@@ -246,10 +246,25 @@ struct PreprocParams {
     float* out;                // [B][3][H][crop_w] fp32
 };
 void launch_preprocess(const PreprocParams& p, hipStream_t s);
+// resize (PIL bilinear, byte-exact) + ToTensor + Normalize + roll + crop (kernels_preproc.hip)
+struct ResizeParams {
+    const unsigned char* in;   // [B][IH][IW][3] uint8
+    int B, IH, IW, OH, OW, crop_w;
+    unsigned char* tmp;        // [B][IH][OW][3] uint8 scratch (the horizontally resampled image)
+    const int* shift;          // [B] roll in output pixels or null
+    float mean[3], stdv[3];
+    float* out;                // [B][3][OH][crop_w] fp32
+};
+int launch_resize(const ResizeParams& p, hipStream_t s);   // -1: down-scaling factor above 8
+
 void launch_scatter_channels(const float* src, int C, long long P, Dst d0, Dst d1, int ndst, hipStream_t s);
 
 struct PoseOut { int32_t index; float prob, cos_v, sin_v, angle_deg; };
 void launch_postprocess(const float* heat, const float* ori, int B, int n, PoseOut* out, hipStream_t s);
+
+struct MetricsOut { double pixel_distance, meter_distance, prob_at_gt, angle_pred_deg, angle_gt_deg, orientation_error_deg, longitudinal_m, lateral_m; };
+void launch_metrics(const PoseOut* pose, const float* heat, int B, int W, int n, const int* gt_index, const float* gt_cos_sin,
+                    const double* meter_per_pixel, const double* heading_deg, MetricsOut* out, hipStream_t s);
 
 void launch_nhwc_to_nchw(const float* in, int in_ld, int coff, int C, int B, int HW, float* out, hipStream_t s);
 

@@ -198,6 +198,55 @@ void launch_postprocess(const float* heat, const float* ori, int B, int n, PoseO
 }
 
 // ------------------------------------------------------------------------------------------------
+// GT-side test-loop metrics (second half): train_VIGOR.py:296-326, train_KITTI.py:309-343.  One thread per
+// query, double precision like the reference's numpy / math code.  Inputs: the pose of postprocess_kernel, the heatmap (for
+// the probability at the ground-truth pixel) and per-query ground truth from the dataset side.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double angle_deg_of(double c, double s) {   // math.acos + the sign rule of train_VIGOR.py:307-311
+    const double a = acos(c) * 57.29577951308232;                       // math.degrees
+    if (s < 0.0) { double m = fmod(-a, 360.0); if (m < 0.0) m += 360.0; return m; }   // Python's % 360
+    return a;
+}
+
+__global__ __launch_bounds__(64) void metrics_kernel(const PoseOut* pose, const float* heat, int B, int W, int n, const int* gt_index,
+                                                     const float* gt_cos_sin, const double* meter_per_pixel, const double* heading_deg,
+                                                     MetricsOut* out) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const int pi = pose[b].index, gi = gt_index[b];
+    const int py = pi / W, px = pi - py * W, gy = gi / W, gx = gi - gy * W;
+    const double dy = (double)(gy - py), dx = (double)(gx - px);
+    MetricsOut m;
+    m.pixel_distance = sqrt(dy * dy + dx * dx);
+    m.meter_distance = m.pixel_distance * meter_per_pixel[b];
+    m.prob_at_gt = (double)heat[(size_t)b * n + gi];
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    const double cp = (double)pose[b].cos_v, sp = (double)pose[b].sin_v;
+    m.angle_pred_deg = m.angle_gt_deg = m.orientation_error_deg = nan;
+    if (fabs(cp) <= 1.0 && fabs(sp) <= 1.0) {    // the reference skips the orientation error otherwise (train_VIGOR.py:306)
+        m.angle_pred_deg = angle_deg_of(cp, sp);
+        if (gt_cos_sin) {
+            m.angle_gt_deg = angle_deg_of((double)gt_cos_sin[2 * b], (double)gt_cos_sin[2 * b + 1]);
+            const double d = fabs(m.angle_gt_deg - m.angle_pred_deg);
+            m.orientation_error_deg = fmin(d, 360.0 - d);
+        }
+    }
+    m.longitudinal_m = m.lateral_m = nan;
+    if (heading_deg) {                            // train_KITTI.py:318-325
+        const double gt2pred = atan2(fabs(dx), fabs(dy)) * 180.0 / 3.141592653589793;
+        const double diff = fabs(heading_deg[b] - gt2pred);
+        m.longitudinal_m = fabs(cos(diff * 3.141592653589793 / 180.0) * m.pixel_distance) * meter_per_pixel[b];
+        m.lateral_m = fabs(sin(diff * 3.141592653589793 / 180.0) * m.pixel_distance) * meter_per_pixel[b];
+    }
+    out[b] = m;
+}
+
+void launch_metrics(const PoseOut* pose, const float* heat, int B, int W, int n, const int* gt_index, const float* gt_cos_sin,
+                    const double* meter_per_pixel, const double* heading_deg, MetricsOut* out, hipStream_t s) {
+    hipLaunchKernelGGL(metrics_kernel, dim3((B + 63) / 64), dim3(64), 0, s, pose, heat, B, W, n, gt_index, gt_cos_sin, meter_per_pixel, heading_deg, out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Input pre-processing: uint8 HWC image (already decoded / resized on the host) ->
 // ToTensor (x/255) -> Normalize((x-mean)/std) (train_VIGOR.py:57-70) -> panorama roll
 // torch.roll(grd, shift, dims=2) (datasets.py:118) -> FoV width crop grd[..., :crop_w]

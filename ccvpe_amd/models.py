@@ -262,6 +262,37 @@ class _CVMBase(nn.Module):
         f = buf.view(torch.float32)
         return {"index": buf[:, 0].to(torch.int64), "prob": f[:, 1], "cos": f[:, 2], "sin": f[:, 3], "angle_deg": f[:, 4]}
 
+    METRIC_FIELDS = ("pixel_distance", "meter_distance", "prob_at_gt", "angle_pred_deg", "angle_gt_deg", "orientation_error_deg",
+                     "longitudinal_m", "lateral_m")
+
+    def evaluate(self, heatmap: torch.Tensor, ori: torch.Tensor, gt_index, meter_per_pixel, gt_cos_sin=None, heading_deg=None
+                 ) -> Dict[str, torch.Tensor]:
+        """Device-side version of the whole per-sample test loop (train_VIGOR.py:290-326, train_KITTI.py:309-343): argmax /
+        orientation lookup (postprocess) plus the ground-truth side - pixel and metre distance, probability at the
+        ground-truth pixel, orientation error, lateral / longitudinal split.  Returns float64 tensors [B] (NaN where the
+        reference produces no value for the query)."""
+        B = heatmap.shape[0]
+        dev = heatmap.device
+        self._ensure_handle(dev)
+        heatmap = heatmap.contiguous()
+        pose = torch.empty((B, 5), dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        lib = _lib.load()
+        _lib.check(lib.ccvpe_postprocess(self._handle, C.c_void_p(heatmap.data_ptr()), C.c_void_p(ori.contiguous().data_ptr()), B,
+                                         C.c_void_p(pose.data_ptr()), C.c_void_p(stream)), "ccvpe_postprocess")
+        gi = torch.as_tensor(gt_index, dtype=torch.int32, device=dev).contiguous()
+        mpp = torch.as_tensor(meter_per_pixel, dtype=torch.float64, device=dev).expand(B).contiguous()
+        gcs = None if gt_cos_sin is None else torch.as_tensor(gt_cos_sin, dtype=torch.float32, device=dev).reshape(B, 2).contiguous()
+        hd = None if heading_deg is None else torch.as_tensor(heading_deg, dtype=torch.float64, device=dev).expand(B).contiguous()
+        out = torch.empty((B, len(self.METRIC_FIELDS)), dtype=torch.float64, device=dev)
+        _lib.check(lib.ccvpe_eval_metrics(self._handle, C.c_void_p(pose.data_ptr()), C.c_void_p(heatmap.data_ptr()), B, C.c_void_p(gi.data_ptr()),
+                                          C.c_void_p(gcs.data_ptr()) if gcs is not None else None, C.c_void_p(mpp.data_ptr()),
+                                          C.c_void_p(hd.data_ptr()) if hd is not None else None, C.c_void_p(out.data_ptr()), C.c_void_p(stream)),
+                   "ccvpe_eval_metrics")
+        res = {k: out[:, i] for i, k in enumerate(self.METRIC_FIELDS)}
+        res["index"] = pose[:, 0].to(torch.int64)
+        return res
+
     def set_streams(self, n: int) -> None:
         """Issue order of later forwards: 2 (default) two-stream schedule, 1 program order (bit-identical results)."""
         self._n_streams = int(n)
@@ -289,7 +320,7 @@ class _CVMBase(nn.Module):
             return host[: n.value].reshape(*[int(s) for s in shape]).clone()
 
     def profile(self, grd: torch.Tensor, sat: torch.Tensor):
-        """One forward with a hipEvent pair around every launch: list of (name, ms, flops, bytes)."""
+        """One forward with a hipEvent pair around every launch: list of (name, ms, flops, bytes, issued_flops)."""
         grd, sat = self._prepare(grd, sat)
         B = grd.shape[0]
         lib = _lib.load()
@@ -300,10 +331,11 @@ class _CVMBase(nn.Module):
         _lib.check(n, "ccvpe_profile_forward")
         rows = []
         name = C.create_string_buffer(128)
-        ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+        ms, fl, by, iss = C.c_float(), C.c_double(), C.c_double(), C.c_double()
         for i in range(n):
             _lib.check(lib.ccvpe_profile_row(self._handle, i, name, 128, C.byref(ms), C.byref(fl), C.byref(by)), "ccvpe_profile_row")
-            rows.append((name.value.decode(), ms.value, fl.value, by.value))
+            _lib.check(lib.ccvpe_profile_row_issued(self._handle, i, C.byref(iss)), "ccvpe_profile_row_issued")
+            rows.append((name.value.decode(), ms.value, fl.value, by.value, iss.value))
         return rows
 
 

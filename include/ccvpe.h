@@ -82,6 +82,19 @@ typedef struct ccvpe_pose {
     float   angle_deg;          /* acos/sign rule of train_VIGOR.py:307-311, in [0, 360) */
 } ccvpe_pose;
 
+/* Per-query evaluation record of the reference test loops (train_VIGOR.py:296-326, train_KITTI.py:309-343), double
+ * precision like their numpy / math arithmetic.  NaN = the reference does not produce that number for the query. */
+typedef struct ccvpe_metrics {
+    double pixel_distance;         /* |argmax(gt) - argmax(heatmap)| in output pixels          train_VIGOR.py:299 */
+    double meter_distance;         /* pixel_distance * meter_per_pixel[b]                       :301-309 */
+    double prob_at_gt;             /* heatmap at the ground-truth pixel                         :326 */
+    double angle_pred_deg;         /* acos / sign rule on the predicted (cos, sin)              :306-311 */
+    double angle_gt_deg;           /* the same on the ground-truth (cos, sin)                   :312-317 */
+    double orientation_error_deg;  /* min(|gt - pred|, 360 - |gt - pred|)                       :319 */
+    double longitudinal_m;         /* KITTI / Oxford: error along the driving direction         train_KITTI.py:322-324 */
+    double lateral_m;              /* ... and across it                                          train_KITTI.py:323-325 */
+} ccvpe_metrics;
+
 const char* ccvpe_last_error(void);
 const char* ccvpe_version(void);
 
@@ -98,6 +111,11 @@ int ccvpe_skip_weight(ccvpe_handle h, const char* key);
  * uploads it.  Fails with CCVPE_EKEY (message lists the first missing key) if any key is unset. */
 int ccvpe_finalize_weights(ccvpe_handle h);
 
+/* Largest micro_batch whose intermediate tensors all stay below the 2 GiB the kernels address with 32-bit byte offsets
+ * (ccvpe_forward refuses a larger one with CCVPE_EINVAL instead of wrapping offsets).  Pure host arithmetic, no device
+ * needed.  Negative on a ground size the variant's descriptor heads cannot take. */
+int ccvpe_max_micro_batch(int32_t variant, float ori_noise, int32_t grd_h, int32_t grd_w);
+
 /* R_k of matching_score[level] (level 0..5) for this handle's variant / ori_noise. */
 int ccvpe_output_channels(ccvpe_handle h, int32_t level);
 /* Device workspace the library holds for a (batch, ground size) plan, in bytes (0 on error). */
@@ -111,6 +129,15 @@ int ccvpe_forward(ccvpe_handle h, const float* grd, int32_t grd_h, int32_t grd_w
 /* Device-side test-loop post-processing on forward outputs: poses[B] is DEVICE memory. */
 int ccvpe_postprocess(ccvpe_handle h, const float* heatmap, const float* ori, int32_t batch,
                       ccvpe_pose* poses, void* stream);
+
+/* Ground-truth side of the same test loop, on device: `poses` from ccvpe_postprocess, `gt_index[B]` = flat index of
+ * argmax(gt map) (y*512 + x), `gt_cos_sin[B][2]` = ground-truth orientation at that pixel (NULL: no orientation error),
+ * `meter_per_pixel[B]` = metres per OUTPUT pixel (VIGOR: city constant / 512 * 640, train_VIGOR.py:301-308; KITTI:
+ * test_set.meter_per_pixel), `heading_deg[B]` = orientation_angle of train_KITTI.py:310 (NULL: no lateral / longitudinal
+ * split).  All pointers are DEVICE memory; out[B] likewise. */
+int ccvpe_eval_metrics(ccvpe_handle h, const ccvpe_pose* poses, const float* heatmap, int32_t batch, const int32_t* gt_index,
+                       const float* gt_cos_sin, const double* meter_per_pixel, const double* heading_deg, ccvpe_metrics* out,
+                       void* stream);
 
 /* Aerial-side caching for streaming (reference datasets.py:306-317 reuses aerial tiles across frames, the
  * reference model still re-encodes them every call): encode once, then run ground encoder + matching +
@@ -130,6 +157,16 @@ int ccvpe_forward_cached(ccvpe_handle h, const float* grd, int32_t grd_h, int32_
 int ccvpe_preprocess(const uint8_t* hwc, int32_t batch, int32_t H, int32_t W, const int32_t* shift, int32_t crop_w,
                      const float mean[3], const float stdv[3], float* out_nchw, void* stream);
 
+/* The same with the resize in front (reference train_VIGOR.py:57-70 transforms.Resize([320,640]) / Resize([512,512]), applied
+ * to PIL images at datasets.py:106, i.e. PIL.Image.resize(BILINEAR)): uint8 HWC images [B,in_h,in_w,3] as decoded ->
+ * Pillow's 8-bit bilinear resampler (triangle filter with support = the down-scaling factor, 22-bit fixed-point taps,
+ * horizontal pass first, uint8 between the passes; byte-identical to PIL) -> ToTensor + Normalize + roll + crop as above ->
+ * float32 NCHW [B,3,out_h,crop_w].  `scratch` is caller-owned DEVICE memory of batch*in_h*out_w*3 bytes (may be NULL when
+ * in_w == out_w).  Down-scaling factors above 8 per axis are refused. */
+int ccvpe_preprocess_resize(const uint8_t* hwc, int32_t batch, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                            const int32_t* shift, int32_t crop_w, const float mean[3], const float stdv[3], uint8_t* scratch,
+                            float* out_nchw, void* stream);
+
 /* Debug taps: when enabled, intermediate tensors of the next forward call stay resident and can be
  * copied out by name as NCHW float32 into HOST memory (`capacity` in floats).  Returns the number
  * of floats written via *n_out.  Names: see DESIGN.md (e.g. "sat_block15", "loc_level6"). */
@@ -141,6 +178,12 @@ int ccvpe_set_streams(ccvpe_handle h, int32_t n_streams);
 int ccvpe_read_tap(ccvpe_handle h, const char* name, float* host_dst, size_t capacity, size_t* n_out,
                    int32_t shape_out[4]);
 
+/* Diagnostic: after a synchronised forward, writes one text line per launch of its plan (name, stream, cross-stream
+ * wait, tile) with an integer checksum of every tensor the launch touches.  Meaningful for plans whose tensors keep
+ * their memory (debug plans, two-stream plans issued either way): diffing two dumps names the first launch whose
+ * output differs.  No reference counterpart. */
+int ccvpe_debug_dump_plan(ccvpe_handle h, const char* path);
+
 /* Per-kernel device timing of the most recent ccvpe_profile_forward call: runs one forward with a
  * hipEvent pair around every launch and reports (name, milliseconds) rows.  Used by bench.py for
  * the roofline line.  Returns the number of rows; row i is copied into name_buf / ms. */
@@ -148,6 +191,10 @@ int ccvpe_profile_forward(ccvpe_handle h, const float* grd, int32_t grd_h, int32
                           int32_t batch, const ccvpe_outputs* out, void* stream);
 int ccvpe_profile_row(ccvpe_handle h, int32_t i, char* name_buf, size_t name_cap, float* ms,
                       double* flops, double* bytes);
+/* FLOPs row i actually issued on the matrix pipe: M / N padded to the launch's tile, K to the packed depth, 16
+ * products per 2x2 tile for the Winograd tiles, three MFMAs per product in bf16x3 mode (`flops` of
+ * ccvpe_profile_row is the algorithmic direct-convolution count). */
+int ccvpe_profile_row_issued(ccvpe_handle h, int32_t i, double* issued_flops);
 
 /* Kernel-level hook for parity tests and tile tuning (not on the product path): one NHWC fp32
  * convolution through the implicit-GEMM MFMA kernel.  in [B,H,W,Cin] (device, Cin % 8 == 0),

@@ -131,16 +131,17 @@ def _decoder_level(x: torch.Tensor, skip: Optional[torch.Tensor], sd: Dict[str, 
 
 
 def forward(variant: str, sd: Dict[str, torch.Tensor], grd: torch.Tensor, sat: torch.Tensor,
-            circular: bool = False, ori_noise: Optional[float] = None, taps: Optional[dict] = None):
+            circular: bool = False, ori_noise: Optional[float] = None, taps: Optional[dict] = None, grad: bool = False):
     """CVM_*.forward (models.py:150-343, 448-652, 752-950, 1051-1244).
 
     Returns the reference 9-tuple (logits_flattened, heatmap, x_ori, ms1..ms6).  `taps`, if a dict,
-    receives intermediate tensors for mismatch localisation.
+    receives intermediate tensors for mismatch localisation.  `grad=True` keeps autograd recording (the reference
+    test loop calls the model without no_grad, train_VIGOR.py:282) - only the timing in bench.py's cpu_baseline uses it.
     """
     v = spec.VARIANTS[variant]
     if variant == "vigor_ori_prior":
         assert ori_noise is not None
-    with torch.no_grad():
+    with torch.set_grad_enabled(grad):
         gvol, _ = encoder(grd, sd, "grd_efficientnet", circular)
         descs = [ground_descriptor(gvol, sd, k) for k in range(1, 7)]
         svol, blocks = encoder(sat, sd, "sat_efficientnet", False)
@@ -204,6 +205,46 @@ def postprocess(heatmap: torch.Tensor, ori: torch.Tensor):
     a = torch.rad2deg(torch.acos(cs.clamp(-1, 1)))
     deg = torch.where(sn < 0, (-a) % 360, a)
     return idx, prob, cs, sn, deg
+
+
+def eval_metrics(heatmap, ori, gt_index, meter_per_pixel, gt_cos_sin=None, heading_deg=None):
+    """Ground-truth side of the test loops, restated line by line with the same numpy / math calls
+    (train_VIGOR.py:296-326; lateral / longitudinal split train_KITTI.py:318-325).  The drivers are scripts, not functions,
+    and need the datasets, so this restatement is parity-unpinned beyond its line-by-line correspondence.
+    heatmap [B,1,H,W], ori [B,2,H,W] numpy float32; gt_index [B] flat argmax of the GT map.  Returns dict of float64 lists
+    (NaN where the reference appends nothing)."""
+    import math
+    import numpy as np
+    B = heatmap.shape[0]
+    W = heatmap.shape[-1]
+    keys = ("pixel_distance", "meter_distance", "prob_at_gt", "angle_pred_deg", "angle_gt_deg", "orientation_error_deg", "longitudinal_m", "lateral_m")
+    out = {k: np.full(B, np.nan) for k in keys}
+    mpp = np.broadcast_to(np.asarray(meter_per_pixel, dtype=np.float64), (B,))
+    for b in range(B):
+        current_pred = heatmap[b]
+        loc_pred = np.unravel_index(current_pred.argmax(), current_pred.shape)
+        loc_gt = (0, int(gt_index[b]) // W, int(gt_index[b]) % W)
+        pixel_distance = np.sqrt((loc_gt[1] - loc_pred[1]) ** 2 + (loc_gt[2] - loc_pred[2]) ** 2)
+        out["pixel_distance"][b] = pixel_distance
+        out["meter_distance"][b] = pixel_distance * mpp[b]
+        cos_pred, sin_pred = ori[b, :, loc_pred[1], loc_pred[2]]
+        if np.abs(cos_pred) <= 1 and np.abs(sin_pred) <= 1:
+            a_acos_pred = math.acos(cos_pred)
+            angle_pred = math.degrees(-a_acos_pred) % 360 if sin_pred < 0 else math.degrees(a_acos_pred)
+            out["angle_pred_deg"][b] = angle_pred
+            if gt_cos_sin is not None:
+                cos_gt, sin_gt = gt_cos_sin[b]
+                a_acos_gt = math.acos(cos_gt)
+                angle_gt = math.degrees(-a_acos_gt) % 360 if sin_gt < 0 else math.degrees(a_acos_gt)
+                out["angle_gt_deg"][b] = angle_gt
+                out["orientation_error_deg"][b] = np.min([np.abs(angle_gt - angle_pred), 360 - np.abs(angle_gt - angle_pred)])
+        out["prob_at_gt"][b] = heatmap[b, 0, loc_gt[1], loc_gt[2]]
+        if heading_deg is not None:
+            gt2pred_from_north = np.arctan2(np.abs(loc_gt[2] - loc_pred[2]), np.abs(loc_gt[1] - loc_pred[1])) * 180 / math.pi
+            angle_diff = np.abs(heading_deg[b] - gt2pred_from_north)
+            out["longitudinal_m"][b] = np.abs(np.cos(angle_diff * np.pi / 180) * pixel_distance) * mpp[b]
+            out["lateral_m"][b] = np.abs(np.sin(angle_diff * np.pi / 180) * pixel_distance) * mpp[b]
+    return out
 
 
 def preprocess(img_u8_hwc, shift=None, crop_w=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):

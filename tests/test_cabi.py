@@ -49,3 +49,17 @@ def test_null_arguments_are_rejected(built_library):
     assert lib.ccvpe_forward(None, None, 0, 0, None, 0, None, None) == -1
     assert lib.ccvpe_destroy(None) == 0
     assert lib.ccvpe_version().startswith(b"ccvpe-hip")
+
+
+def test_micro_batch_bound_is_host_arithmetic():
+    """Every kernel addresses tensors with 32-bit byte offsets; the library must refuse (not wrap) a micro-batch whose
+    largest tensor reaches 2 GiB.  ccvpe_max_micro_batch is pure host code: the 6x-expanded 256x256x96 tensor of the
+    aerial encoder (25.2 MB per sample) caps every variant at 85 samples per pass."""
+    from ccvpe_amd import _lib
+    lib = _lib.load()
+    for variant, noise, gh, gw in [(0, 0.0, 320, 640), (1, 180.0, 320, 640), (1, 72.0, 320, 192), (2, 0.0, 256, 1024), (3, 0.0, 154, 231)]:
+        cap = lib.ccvpe_max_micro_batch(variant, noise, gh, gw)
+        assert cap == (2 ** 31 - 1) // (256 * 256 * 96 * 4), (variant, cap)
+    assert lib.ccvpe_max_micro_batch(2, 0.0, 250, 1024) < 0          # 7 feature rows: not a KITTI-shaped ground image
+    assert b"feature volume" in lib.ccvpe_last_error()
+    assert lib.ccvpe_max_micro_batch(7, 0.0, 320, 640) < 0

@@ -86,3 +86,80 @@ def test_postprocess_argmax_ties_take_the_first_index_like_numpy():
     np.testing.assert_array_equal(idx, [4099, 4, 0, n - 1])
     np.testing.assert_array_equal(post["prob"].cpu().numpy(), flat.max(axis=1))
     np.testing.assert_allclose(post["angle_deg"].cpu().numpy(), want[4].numpy(), rtol=1e-5, atol=1e-3)
+
+
+def _resize_reference(img_u8, oh, ow, shift, crop_w):
+    """oracle: Pillow-exact resize (numpy) then the ToTensor / Normalize / roll / crop restatement."""
+    from oracle import ccvpe_oracle as orc
+    from oracle import resize_oracle as ro
+    rs = np.stack([ro.resize_bilinear_u8(im, oh, ow) for im in img_u8])
+    return orc.preprocess(torch.from_numpy(rs), shift, crop_w)
+
+
+def test_resize_preprocess_matches_pillow_fixture_bit_for_bit():
+    """resize inside the pre-processing kernels.  Expected bytes come from Pillow itself
+    (tests/golden/resize.npz); the float stage must equal torchvision's (x/255 - mean)/std exactly."""
+    from ccvpe_amd import _lib
+    from oracle import ccvpe_oracle as orc
+    fx = np.load(gu.GOLDEN_DIR + "/resize.npz", allow_pickle=False)
+    i = 0
+    while f"in{i}" in fx:
+        img, want = fx[f"in{i}"], fx[f"out{i}"]
+        got = _lib.preprocess_resize(torch.from_numpy(img[None]).cuda(), want.shape[:2])
+        ref = orc.preprocess(torch.from_numpy(want[None]))
+        assert got.shape == ref.shape
+        assert torch.equal(got.cpu(), ref), f"case {i}: {img.shape} -> {want.shape}"
+        i += 1
+    assert i >= 7
+
+
+def test_resize_preprocess_full_vigor_geometry_with_roll_and_crop():
+    """1024 x 2048 panoramas -> 320 x 640 with a per-sample roll and the HFoV-108 crop, and 640 x 640 aerial tiles -> 512 x 512:
+    bit-identical to the oracle (numpy restatement of Pillow, pinned by tests/test_resize_oracle.py)."""
+    from ccvpe_amd import _lib
+    rng = np.random.default_rng(3)
+    pano = rng.integers(0, 256, size=(2, 1024, 2048, 3), dtype=np.uint8)
+    shift = [197, -45]
+    got = _lib.preprocess_resize(torch.from_numpy(pano).cuda(), (320, 640), shift=shift, crop_w=192)
+    assert torch.equal(got.cpu(), _resize_reference(pano, 320, 640, shift, 192))
+    sat = rng.integers(0, 256, size=(2, 640, 640, 3), dtype=np.uint8)
+    got = _lib.preprocess_resize(torch.from_numpy(sat).cuda(), (512, 512))
+    assert torch.equal(got.cpu(), _resize_reference(sat, 512, 512, None, None))
+    # an axis that keeps its size is not resampled (Pillow skips the pass): width-only and height-only
+    img = rng.integers(0, 256, size=(1, 96, 200, 3), dtype=np.uint8)
+    assert torch.equal(_lib.preprocess_resize(torch.from_numpy(img).cuda(), (96, 64)).cpu(), _resize_reference(img, 96, 64, None, None))
+    assert torch.equal(_lib.preprocess_resize(torch.from_numpy(img).cuda(), (40, 200)).cpu(), _resize_reference(img, 40, 200, None, None))
+    with pytest.raises(_lib.CcvpeError):
+        _lib.preprocess_resize(torch.from_numpy(img).cuda(), (8, 8))       # 12x / 25x down-scaling: refused, not truncated
+
+
+def test_ground_truth_side_metrics_match_the_restated_test_loop():
+    """SURVEY 8f row 1, second half: pixel -> metre distance, probability at the GT pixel, orientation error and the KITTI
+    lateral / longitudinal split on device, against the line-by-line numpy restatement of train_VIGOR.py:296-326 /
+    train_KITTI.py:318-325 (oracle/ccvpe_oracle.py eval_metrics)."""
+    cfg = gu.CONFIGS["kitti"]
+    m = models.CVM_KITTI("cuda")
+    m.load_state_dict(weights.generate_state_dict("kitti", 0))
+    m.to("cuda").eval()
+    B = 6
+    g, s = weights.generate_inputs("kitti", B, 4)
+    outs = m(torch.from_numpy(g).cuda(), torch.from_numpy(s).cuda())
+    heat, ori = outs[1], outs[2]
+    rng = np.random.default_rng(0)
+    gt_index = rng.integers(0, 512 * 512, size=B)
+    gt_index[0] = int(heat[0].flatten().argmax())          # a perfect hit: distance 0, atan2(0, 0)
+    ang = rng.uniform(0, 2 * np.pi, size=B)
+    gt_cs = np.stack([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32)
+    mpp = rng.uniform(0.1, 0.3, size=B)
+    heading = rng.uniform(-180, 180, size=B)
+    got = m.evaluate(heat, ori, gt_index, mpp, gt_cs, heading)
+    ref = orc.eval_metrics(heat.cpu().numpy(), ori.cpu().numpy(), gt_index, mpp, gt_cs, heading)
+    for k, v in ref.items():
+        gk = got[k].cpu().numpy()
+        assert np.array_equal(np.isnan(gk), np.isnan(v)), k
+        assert np.allclose(gk, v, rtol=1e-9, atol=1e-7, equal_nan=True), (k, gk, v)
+    # VIGOR form: no heading -> no lateral / longitudinal numbers; scalar metres-per-pixel broadcast
+    got = m.evaluate(heat, ori, gt_index, 0.113248 / 512 * 640, gt_cs)
+    ref = orc.eval_metrics(heat.cpu().numpy(), ori.cpu().numpy(), gt_index, 0.113248 / 512 * 640, gt_cs)
+    assert torch.isnan(got["lateral_m"]).all()
+    assert np.allclose(got["meter_distance"].cpu().numpy(), ref["meter_distance"], rtol=1e-12)

@@ -1,0 +1,106 @@
+"""Wider parity coverage (round 2): full tensors, not just the golden lattice, for all four variants - including the
+un-normalised orientation map and the unit (cos, sin) field - plus batch-32 property tests for BASELINE.json configs 3
+(VIGOR HFoV 108 / ori_noise 72) and 4 (KITTI) and a full-tensor run of the opt-in bf16x3 mode.
+
+The checker is the CPU oracle (oracle/ccvpe_oracle.py, pinned to the reference by tests/test_oracle_vs_reference.py and
+the committed goldens); the product path goes through the C ABI.  Tolerances: BASELINE.json north_star asks 1e-3 relative
+fp32; full tensors are held to 5e-4 of each tensor's max |value| (the lattice tests to 1e-4): they include the
+worst-conditioned cosine scores (near-cancelling dot products over up to 1280 terms)."""
+import numpy as np
+import pytest
+import torch
+
+from ccvpe_amd import models, weights
+from tests import golden_util as gu
+from tests.test_parity_gpu import build_model, inputs
+
+pytestmark = pytest.mark.gpu
+
+FULL_RTOL = 5e-4
+CONTRACT_RTOL = 1e-3
+
+
+def _oracle(cfg, sd, g, s, taps=None):
+    from oracle import ccvpe_oracle as orc   # checker only
+    return orc.forward(cfg["variant"], sd, torch.from_numpy(g), torch.from_numpy(s), cfg["circular"], cfg["ori_noise"], taps=taps)
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(a.abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize("name,precision", [("vigor_prior180_circ", "fp32"), ("vigor_prior72_fov108", "fp32"), ("vigor_circ", "fp32"),
+                                            ("kitti", "fp32"), ("oxford", "fp32"), ("vigor_prior180_circ", "bf16x3"), ("kitti", "bf16x3")])
+def test_full_tensors_match_the_oracle(name, precision):
+    cfg = gu.CONFIGS[name]
+    seed = 21
+    sd = weights.generate_state_dict(cfg["variant"], seed)
+    g, s = weights.generate_inputs(cfg["variant"], 2, seed, cfg["fov"])
+    taps = {}
+    ref = _oracle(cfg, sd, g, s, taps)
+    m = build_model(dict(cfg, seed=seed), precision=precision)
+    m.set_debug(True)            # keeps the un-normalised orientation map (tap ori_level1_nchw)
+    outs = m(torch.from_numpy(g).cuda(), torch.from_numpy(s).cuda())
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(ref, outs)):
+        if i == 2:
+            continue
+        assert a.shape == b.shape, gu.OUTPUT_NAMES[i]
+        err = _rel(a, b.cpu())
+        worst = max(worst, err)
+        assert err <= FULL_RTOL, f"{gu.OUTPUT_NAMES[i]}: {err:.3g}"
+    # orientation: the raw 2-channel map everywhere, then the unit field weighted by the raw magnitude (F.normalize is
+    # ill-conditioned where the raw vector is ~0: a last-bit change of the input flips the direction there)
+    raw_ref = taps["ori_level1"]
+    raw = m.read_tap("ori_level1_nchw")
+    assert raw.shape == raw_ref.shape
+    err = _rel(raw_ref, raw)
+    assert err <= FULL_RTOL, f"ori (un-normalised): {err:.3g}"
+    mag = raw_ref.pow(2).sum(dim=1, keepdim=True).sqrt()
+    werr = ((ref[2] - outs[2].cpu()).abs() * mag).max().item() / mag.max().item()
+    assert werr <= FULL_RTOL, f"ori (magnitude-weighted): {werr:.3g}"
+    norm = outs[2].double().pow(2).sum(dim=1).sqrt()
+    assert (norm - 1).abs().max().item() < 1e-4
+    assert max(worst, err, werr) <= CONTRACT_RTOL
+
+
+@pytest.mark.parametrize("name", ["vigor_prior72_fov108", "kitti"])
+def test_batch32_properties_configs_3_and_4(name):
+    """BASELINE.json configs 3 and 4 at their full batch: size-independent properties, consistency of sample i of the batch
+    with a batch-1 run of the same sample (through a different plan: hipGraph replay, split-K tiles), permutation
+    equivariance, and the post-processing against a numpy restatement of train_VIGOR.py:297-316."""
+    cfg = gu.CONFIGS[name]
+    m = build_model(cfg)
+    g, s = inputs(cfg, batch=32)
+    outs = m(g, s)
+    logits, heat, ori = outs[0], outs[1], outs[2]
+    assert all(torch.isfinite(o).all() for o in outs)
+    sums = heat.double().sum(dim=(1, 2, 3))
+    assert torch.allclose(sums, torch.ones_like(sums), atol=1e-4)
+    assert torch.allclose(heat.flatten(1), torch.softmax(logits, dim=1), rtol=2e-4, atol=1e-9)
+    assert ((ori.double().pow(2).sum(dim=1).sqrt()) - 1).abs().max().item() < 1e-4
+    R = 9 if name == "vigor_prior72_fov108" else 16
+    assert outs[3].shape[1] == (20 if name == "vigor_prior72_fov108" else 16)      # level 1 always carries the full roll set
+    for k in range(1, 6):
+        assert outs[3 + k].shape == (32, R, 8 << k, 8 << k)
+        assert outs[3 + k].abs().max().item() <= 1.0 + 1e-5
+    if name == "kitti":
+        # roll periods shorter than 16: level 2-4 period 8, level 6 period 4 -> exact duplicates
+        for lvl, period in ((2, 8), (3, 8), (4, 8), (6, 4)):
+            t = outs[2 + lvl]
+            assert torch.equal(t[:, :period], t[:, period:2 * period]), f"ms{lvl}: channels repeat with period {period}"
+    for i in (0, 13, 31):
+        one = m(g[i:i + 1], s[i:i + 1])
+        for j, (a, b) in enumerate(zip(outs, one)):
+            if j != 2:
+                assert (a[i:i + 1] - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-30), f"sample {i} output {j}"
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(5)).cuda()
+    outs_p = m(g[perm], s[perm])
+    assert (outs_p[0] - logits[perm]).abs().max().item() <= 2e-5 * logits.abs().max().item()
+    post = m.postprocess(heat, ori)
+    hn, on = heat.cpu().numpy(), ori.cpu().numpy()
+    idx = hn.reshape(32, -1).argmax(axis=1)
+    assert np.array_equal(post["index"].cpu().numpy(), idx)
+    yy, xx = idx // 512, idx % 512
+    assert np.allclose(post["cos"].cpu().numpy(), on[np.arange(32), 0, yy, xx], atol=1e-6)
+    assert np.allclose(post["sin"].cpu().numpy(), on[np.arange(32), 1, yy, xx], atol=1e-6)
