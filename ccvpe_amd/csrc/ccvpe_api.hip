@@ -120,6 +120,8 @@ struct PackedConv {
     float* wino = nullptr;        // Winograd-domain weights of a 3x3 layer (kernels_wino.hip), fp32 mode only
     int wino_n16 = 0;
     size_t wino_bytes = 0;
+    float* wino4 = nullptr;       // F(4x4,3x3) weights (kernels_wino4.hip): wide layers on maps up to 128 x 128 only
+    size_t wino4_bytes = 0;
 };
 struct BlockW {
     PackedConv expand, project;
@@ -180,6 +182,7 @@ struct Op {
     int conv_cin = 0;             // 3x3 layers: input channels (issued-FLOP accounting of the Winograd tiles)
     bool bf16x3_only = false;     // the launch reads a pre-split bf16 tensor: exact-fp32 tiles cannot serve it
     bool wino_ok = false;         // 3x3 / stride 1 layer with Winograd-domain weights packed
+    bool wino4_ok = false;        // ... with the F(4x4,3x3) weights packed as well
     // two-stream execution (Plan::schedule): stream the op is issued on, ops of the other stream it must wait for,
     // and whether an op of the other stream waits for this one (then an event is recorded after it)
     int stream = 0;
@@ -455,6 +458,14 @@ static int pack_conv(ccvpe_handle_s* h, PackedConv& pc, int N, int taps, int cin
         conv_wino_pack(N, cin, get, u, &pc.wino_n16);
         pc.wino_bytes = u.size() * sizeof(float);
         if ((rc = upload(h, u, &pc.wino))) return rc;
+        // F(4x4,3x3) pays where the layer is matrix-pipe bound and fills 64-channel slices: >= 64 output channels
+        // (4x the direct weights: ~0.5 GB for the layers that qualify)
+        if (N >= 64 && (size_t)((cin + 15) / 16) * 4 * 9 * ((N + 15) / 16) * 1024 < (1u << 31) && !getenv("CCVPE_NO_WINO4")) {
+            std::vector<float> u4;
+            conv_wino4_pack(N, cin, get, u4);
+            pc.wino4_bytes = u4.size() * sizeof(float);
+            if ((rc = upload(h, u4, &pc.wino4))) return rc;
+        }
     }
     if (h->cfg.reserved[0] == 1) {   // bf16x3: hi = bf16(w), lo = bf16(w - hi), round to nearest even
         auto to_bf16 = [](float f) -> unsigned short {
@@ -648,6 +659,7 @@ static ConvParams conv_params(const PackedConv& pc, const float* in, int in_ld, 
     p.gate_bytes = (unsigned)((size_t)B * pc.cinp * sizeof(float));
     p.w_plane_bytes = (unsigned)((size_t)p.Npad * pc.Kpad * sizeof(unsigned short));
     p.wino_w = pc.wino; p.wino_n16 = pc.wino_n16; p.wino_bytes = (unsigned)pc.wino_bytes;
+    p.wino4_w = pc.wino4; p.wino4_bytes = (unsigned)pc.wino4_bytes;
     return p;
 }
 
@@ -925,6 +937,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
             pl.ops.back().bf16x3_only = cat.split;
             pl.ops.back().conv_cin = cat.C;
             pl.ops.back().wino_ok = pc->wino != nullptr && !cat.split && h->wino && h->cfg.reserved[0] == 0;
+            pl.ops.back().wino4_ok = pl.ops.back().wino_ok && pc->wino4 != nullptr;
         }
         if (j == 5) return mid;   // tail conv handled by the caller
         Tensor o = pl.alloc(B, hout, hout, l.out);
@@ -939,6 +952,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
             pl.ops.back().bf16x3_only = mid.split;
             pl.ops.back().conv_cin = mid.C;
             pl.ops.back().wino_ok = pc->wino != nullptr && !mid.split && h->wino && h->cfg.reserved[0] == 0;
+            pl.ops.back().wino4_ok = pl.ops.back().wino_ok && pc->wino4 != nullptr;
         }
         return o;
     };
@@ -1294,6 +1308,7 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
                 if (conv_igemm_tile_is_bf16x3(t) && !std::strstr(conv_igemm_tile_name(t), only)) continue;
             if (op.bf16x3_only && !conv_igemm_tile_is_bf16x3(t)) continue;
             if (conv_igemm_tile_is_wino(t) && !op.wino_ok) continue;
+            if (conv_igemm_tile_is_wino4(t) && !op.wino4_ok) continue;
             const long long blocks = conv_igemm_tile_blocks(q, t);
             static const bool no_split = getenv("CCVPE_TUNE_SPLITK") && std::atoi(getenv("CCVPE_TUNE_SPLITK")) == 0;
             for (int split = 1; split <= (no_split ? 1 : 16); split *= 2) {
@@ -1525,7 +1540,8 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
                     q.M = op.gemm_m; q.N = op.gemm_n;
                     const double util = conv_igemm_tile_util(q, tile & 0xff);
                     const double mn_pad = util > 0 ? (double)op.gemm_m * op.gemm_n / util : 0.0;
-                    if (conv_igemm_tile_is_wino(tile)) issued = 2.0 * mn_pad * 4.0 * op.conv_cin;
+                    if (conv_igemm_tile_is_wino4(tile)) issued = 2.0 * mn_pad * 2.25 * ((op.conv_cin + 15) / 16 * 16);   // 36 products per 4x4 tile
+                    else if (conv_igemm_tile_is_wino(tile)) issued = 2.0 * mn_pad * 4.0 * op.conv_cin;
                     else issued = 2.0 * mn_pad * op.gemm_kpad * (conv_igemm_tile_is_bf16x3(tile) ? 3.0 : 1.0);
                 }
                 h->prof.push_back({nm, ms, op.flops, op.bytes, issued});
@@ -1782,7 +1798,14 @@ int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Ci
     ConvParams p = conv_params(pc, in, Cin, B, H, W, OH, OW, stride, pad, pad, act);
     p.dst[0] = {out, Cout, 0}; p.ndst = 1;
     hipStream_t st = (hipStream_t)stream;
-    if (conv_igemm_tile_is_wino(tile) && !conv_wino_supported(p)) { cleanup(); return fail(CCVPE_EINVAL, "layer is not Winograd-shaped (3x3, stride 1, pad 1, W %% 16 == 0, H %% 16 == 0)"); }
+    if (((tile >> 8) & 0xff) > 1) {   // tile word = id | (split-K << 8): give the launch a slab
+        const size_t fl = (size_t)((tile >> 8) & 0xff) * p.M * p.N;
+        void* d = nullptr;
+        if (hipMalloc(&d, fl * sizeof(float)) != hipSuccess) { cleanup(); return fail(CCVPE_ENOMEM, "split-K slab"); }
+        tmp.dev_allocs.push_back(d);
+        p.partial = (float*)d; p.partial_floats = fl;
+    }
+    if (conv_igemm_tile_is_wino(tile) && !conv_wino_tile_supported(p, tile)) { cleanup(); return fail(CCVPE_EINVAL, "layer is not Winograd-shaped (3x3, stride 1, pad 1, W %% 16 == 0, H %% 16 == 0; F(4x4): >= 64 output channels)"); }
     if (launch_conv_igemm(p, tile, st) != 0) { cleanup(); return fail(CCVPE_EINVAL, "unsupported conv geometry (KH*KW <= 16, Cin %% 8 == 0)"); }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && iters > 0 && ms) {

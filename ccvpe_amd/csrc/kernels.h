@@ -73,6 +73,9 @@ struct ConvParams {
     const float* wino_w;       // [Cin/8][16][wino_n16][128]
     int wino_n16;              // ceil(N / 16)
     unsigned wino_bytes;
+    // Winograd F(4x4,3x3) form (kernels_wino4.hip), packed for the wide decoder layers only; null = not packed
+    const float* wino4_w;      // [ceil(Cin/16)*4 k-steps][9 xi quads][wino_n16][64 lanes][4]
+    unsigned wino4_bytes;
 };
 
 // tile = 0 picks automatically from (M, N); otherwise one of the TILE_* ids.
@@ -89,10 +92,15 @@ void launch_splitk_reduce(const ConvParams& p, hipStream_t s);
 struct Bf16x3Tile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); };
 int bf16x3_num_tiles();
 const Bf16x3Tile* bf16x3_tile(int i);
-struct WinoTile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); };
+struct WinoTile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); int f; };   // f: output tile edge, 2 or 4
 int wino_num_tiles();
 const WinoTile* wino_tile(int i);
 bool conv_wino_supported(const ConvParams& p);
+bool conv_wino4_supported(const ConvParams& p);
+bool conv_wino_tile_supported(const ConvParams& p, int tile);   // the form tile id `tile` needs is packed and the layer is shaped for it
+bool conv_igemm_tile_is_wino4(int tile);
+void launch_wino4_64(const ConvParams& p, hipStream_t s);
+size_t conv_wino4_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out);
 bool conv_igemm_tile_is_wino(int tile);
 size_t conv_wino_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out, int* n16_out);
 int conv_igemm_last_tile();  // tile id of the most recent launch on this thread (then reset to 0)

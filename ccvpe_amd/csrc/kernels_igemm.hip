@@ -324,6 +324,11 @@ static constexpr int NTILES = (int)(sizeof(TILES) / sizeof(TILES[0]));
 int conv_igemm_npad() { return 128; }
 int conv_igemm_num_tiles() { return NTILES + bf16x3_num_tiles() + wino_num_tiles(); }
 bool conv_igemm_tile_is_wino(int tile) { tile &= 0xff; return tile > NTILES + bf16x3_num_tiles() && tile <= conv_igemm_num_tiles(); }
+bool conv_igemm_tile_is_wino4(int tile) { return conv_igemm_tile_is_wino(tile) && wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->f == 4; }
+bool conv_wino_tile_supported(const ConvParams& p, int tile) {
+    if (!conv_igemm_tile_is_wino(tile)) return false;
+    return conv_igemm_tile_is_wino4(tile) ? conv_wino4_supported(p) : conv_wino_supported(p);
+}
 bool conv_igemm_tile_is_bf16x3(int tile) { tile &= 0xff; return tile > NTILES && tile <= NTILES + bf16x3_num_tiles(); }
 static void tile_dims(int tile, int& bm, int& bn) {
     if (tile >= 1 && tile <= NTILES) { bm = TILES[tile - 1].bm; bn = TILES[tile - 1].bn; }
@@ -446,7 +451,7 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
     int splitk = (tile >> 8) & 0xff;
     tile &= 0xff;
     if (conv_igemm_tile_is_bf16x3(tile) && (p.w_hi == nullptr || p.w_lo == nullptr)) tile = 0;   // planes not packed: fp32 path
-    if (conv_igemm_tile_is_wino(tile) && !conv_wino_supported(p)) tile = 0;   // not a Winograd-shaped layer: implicit GEMM
+    if (conv_igemm_tile_is_wino(tile) && !conv_wino_tile_supported(p, tile)) tile = 0;   // not a Winograd-shaped layer: implicit GEMM
     if (tile < 1 || tile > conv_igemm_num_tiles()) tile = pick_tile(p);
     if (p.in_split) {   // pre-split bf16 input: only the bf16x3 kernels can read it
         if (p.w_hi == nullptr) return -1;

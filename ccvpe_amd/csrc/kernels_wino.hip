@@ -351,11 +351,13 @@ static void launch_wino(const ConvParams& p, hipStream_t s) {
 
 // bm = output pixels per workgroup (32 tiles x 4 pixels per set), bn = output channels per workgroup
 static const WinoTile WINO_TILES[] = {
-    {256, 32, "conv_wino_64x32", launch_wino<2, 2, 2>},
-    {128, 48, "conv_wino_32x48", launch_wino<3, 1, 2>},
-    {128, 64, "conv_wino_32x64", launch_wino<4, 1, 4>},
-    {128, 80, "conv_wino_32x80", launch_wino<5, 1, 4>},
-    {256, 48, "conv_wino_64x48", launch_wino<3, 2, 2>},
+    {256, 32, "conv_wino_64x32", launch_wino<2, 2, 2>, 2},
+    {128, 48, "conv_wino_32x48", launch_wino<3, 1, 2>, 2},
+    {128, 64, "conv_wino_32x64", launch_wino<4, 1, 4>, 2},
+    {128, 80, "conv_wino_32x80", launch_wino<5, 1, 4>, 2},
+    {256, 48, "conv_wino_64x48", launch_wino<3, 2, 2>, 2},
+    // F(4x4,3x3), kernels_wino4.hip: 16 tiles of 4x4 pixels x 64 channels per workgroup
+    {256, 64, "conv_wino4_16x64", launch_wino4_64, 4},
 };
 int wino_num_tiles() { return (int)(sizeof(WINO_TILES) / sizeof(WINO_TILES[0])); }
 const WinoTile* wino_tile(int i) { return &WINO_TILES[i]; }

@@ -1,0 +1,362 @@
+// Winograd F(4x4, 3x3) convolution on the fp32 matrix cores of gfx950, fully fused (no transformed tensors in HBM).
+//
+// Serves the WIDE decoder double_conv layers of the reference (models.py:42-47: conv6 / conv5 / conv4 and their _ori
+// twins, conv3_ori; models.py:407-446) where the matrix pipe is the bound:  Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A
+// on 4x4 output tiles needs 36 multiplies per tile and channel pair instead of 144 - 4x fewer matrix-core cycles than
+// the direct form, 1.78x fewer than the F(2x2,3x3) kernel (kernels_wino.hip).  Everything stays fp32; the weights are
+// transformed once on the host in double precision.  The larger transform constants (up to 8) cost accuracy:
+// ~1.4e-5 of the output scale per layer against fp64 (F(2x2): 7e-7, implicit GEMM: 4e-7) - tests/test_ops_gpu.py
+// holds every tile to 1e-4, the path's contract is 1e-3.
+//
+// Work decomposition: a workgroup of 4 wave64 owns a 16 x 16 pixel block of one image (4 x 4 tiles = the 16 rows of
+// one v_mfma_f32_16x16x4_f32) x 64 output channels (16 per wave), for all 36 Winograd positions xi: 144 accumulator
+// registers per lane, so the inverse transform is a per-lane affair.  K is walked in groups of 16 input channels:
+//   * the raw 18 x 18 x 16 patch is staged channel-major in LDS (plane stride 385, row pitch 20: the 64 lanes of a
+//     transform wave hit 64 different banks);
+//   * wave w transforms channels 4w..4w+3 of the group: one (channel, tile) item per lane, 18 ds_read2_b32, B^T d B in
+//     registers, 18 ds_write_b64 into the V image [k-step][xi pair][A-fragment lane][2];
+//   * every wave then runs, per k-step (4 channels), 36 MFMAs from 18 ds_read_b64 (two xi per read); the weights never
+//     touch LDS: the host layout [k-step][xi/4][16-channel slice][lane][xi%4] is the B-fragment layout of four xi, so
+//     a lane loads its 16 bytes straight into the MFMA operand registers, refilled for the next k-step as soon as a
+//     quad's MFMAs have issued.
+// Two barriers per group (V image single-buffered, 61.5 KB of LDS -> two workgroups per CU cover each other's
+// transform phase); the next group's raw patch is in flight under the MFMA phase.  Persistent XCD-aware grid and
+// split-K exactly as kernels_wino.hip.
+#include "igemm_common.h"
+
+#include <algorithm>
+#include <thread>
+
+namespace ccvpe {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+static constexpr int W4_PITCH = 20;                 // floats per raw row (18 used)
+static constexpr int W4_PLANE = 385;                // floats per raw channel plane (18 * 20 = 360, padded to 1 mod 64)
+static constexpr int W4_GCH = 16;                   // input channels per group (4 k-steps)
+static constexpr int W4_VFLOATS = 4 * 18 * 64 * 2;  // V image: [k-step][xi pair][lane][2]
+static constexpr int W4_RAW_F4 = 18 * 18 * 4;       // float4 items of one raw group
+
+// 1-D input transform B^T (Lavin & Gray, points 0, +-1, +-2, inf)
+__device__ __forceinline__ void w4_bt(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
+                                      float& t0, float& t1, float& t2, float& t3, float& t4, float& t5) {
+    const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
+    const float c = d4 - d2, e = d3 - d1;
+    t0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    t1 = a + b;
+    t2 = a - b;
+    t3 = fmaf(2.f, e, c);
+    t4 = fmaf(-2.f, e, c);
+    t5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+}
+// 1-D output transform A^T
+__device__ __forceinline__ void w4_at(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5,
+                                      float& y0, float& y1, float& y2, float& y3) {
+    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    y0 = m0 + s1 + s2;
+    y1 = fmaf(2.f, d2, d1);
+    y2 = fmaf(4.f, s2, s1);
+    y3 = fmaf(8.f, d2, d1) + m5;
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino4_kernel(const ConvParams p) {
+    static_assert(NW == 4, "one transform wave per k-step of a 16-channel group");
+    constexpr int NT = NW * 64;
+    constexpr int RAW_ITEMS = (W4_RAW_F4 + NT - 1) / NT;   // 6
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Vs = smem;                 // [4][18][64][2]
+    float* Rs = smem + W4_VFLOATS;    // [16][W4_PLANE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    const int mbx = p.W >> 4, mby = p.H >> 4;
+    const int mblocks = p.B * mbx * mby;
+    const int total = mblocks * ((p.wino_n16 + NW - 1) / NW);
+
+    // persistent work loop (see kernels_wino.hip): XCD x owns a contiguous run of items, channel block slowest
+    const int xcd = blockIdx.x & 7;
+    const int stride = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+    const int item_begin = xcd * (total >> 3) + min(xcd, total & 7);
+    const int item_end = item_begin + (total >> 3) + (xcd < (total & 7) ? 1 : 0);
+    int item = item_begin + ((int)blockIdx.x >> 3);
+    if (item >= item_end) return;
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wino4_w), 0, p.wino4_bytes, 0x00020000);
+
+    int nb, b, by, bx;
+#define CCVPE_W4_DECODE(it_, nb_, b_, by_, bx_)                                                          \
+    {                                                                                                    \
+        nb_ = (it_) / mblocks;                                                                           \
+        const int mb_ = (it_) - nb_ * mblocks;                                                           \
+        b_ = mb_ / (mbx * mby);                                                                          \
+        const int rem_ = mb_ - b_ * (mbx * mby);                                                         \
+        by_ = rem_ / mbx;                                                                                \
+        bx_ = rem_ - by_ * mbx;                                                                          \
+    }
+    CCVPE_W4_DECODE(item, nb, b, by, bx);
+
+    // ---- raw patch staging: float4 j = tid + i*NT -> pixel j / 4 of the 18 x 18 region, channels 4 * (j % 4) of the group
+    // (register budget: 144 accumulators + 36 weight registers leave ~70 for everything else at two waves per SIMD, so the
+    //  LDS offset of an item is recomputed when it is stored and the patch travels in two halves of three float4)
+    unsigned r_off[RAW_ITEMS];
+    const int r_ch = (tid & 3) * 4;   // first channel inside the group (NT % 4 == 0: the same for every item of a thread)
+    const int r_px0 = tid >> 2;       // pixel of item 0; item i is pixel r_px0 + 64 i
+#define CCVPE_W4_ROFF(b_, by_, bx_, live_)                                                               \
+    _Pragma("unroll") for (int i = 0; i < RAW_ITEMS; ++i) {                                              \
+        const int j = tid + i * NT;                                                                      \
+        const int px = j >> 2, q = j & 3;                                                                \
+        const int py = px / 18, pxx = px - py * 18;                                                      \
+        const int y = (by_) * 16 - 1 + py, x = (bx_) * 16 - 1 + pxx;                                     \
+        const bool ok = (live_) && j < W4_RAW_F4 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W; \
+        r_off[i] = ok ? (unsigned)(((((b_) * p.H + y) * p.W + x) * p.in_ld + q * 4) * 4) : OOB;          \
+    }
+    CCVPE_W4_ROFF(b, by, bx, true);
+
+    // ---- transform item of this lane: channel 4*wave + (lane & 3) of the group, tile (ty, tx) = (lane >> 4, (lane >> 2) & 3)
+    const int tk = lane & 3, ttx = (lane >> 2) & 3, tty = lane >> 4;
+    const float* t_src = Rs + (4 * wave + tk) * W4_PLANE + (4 * tty) * W4_PITCH + 4 * ttx;
+    // V position of the item = A-fragment lane (k * 16 + tile); xi pair xp lives 128 floats further per step
+    float* t_dst = Vs + ((wave * 18) * 64 + tk * 16 + tty * 4 + ttx) * 2;
+
+    // weights: [k-step][xi/4][n16 slice][lane][xi%4], one 16-byte load per (k-step, quad)
+    const unsigned w_quad_b = (unsigned)p.wino_n16 * 1024u;      // bytes between consecutive quads
+    const unsigned w_step_b = w_quad_b * 9u;                     // bytes per k-step
+#define CCVPE_W4_WBASE(nb_) ((nb_) * NW + wave < p.wino_n16 ? (unsigned)((nb_) * NW + wave) * 1024u + (unsigned)lane * 16u : OOB)
+    unsigned w_base = CCVPE_W4_WBASE(nb);
+
+    // split-K over channel groups (blockIdx.z)
+    const int ngr_all = (p.Cin + W4_GCH - 1) / W4_GCH;
+    int g_begin = 0, g_end = ngr_all;
+    if (p.splitk > 1) {
+        const int per = (ngr_all + p.splitk - 1) / p.splitk;
+        g_begin = min((int)blockIdx.z * per, ngr_all);
+        g_end = min(g_begin + per, ngr_all);
+    }
+    if (g_begin >= g_end) return;   // empty split-K slice (the host never launches one)
+
+    f32x4 raw[3];
+    float bq[36];             // B fragments of the current k-step, refilled in place for the next one
+    // channels past Cin (last group of a layer whose Cin is not a multiple of 16) are forced to zero
+#define CCVPE_W4_LOAD_RAW(c0, half)   /* items 3*half .. 3*half+2 */                                     \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                      \
+        const unsigned o_ = ((c0) + r_ch < p.Cin) ? r_off[3 * (half) + i] : OOB;                         \
+        raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, o_, (c0) * 4, 0)); \
+    }
+#define CCVPE_W4_STORE_RAW(half)                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                      \
+        const int px_ = r_px0 + 64 * (3 * (half) + i);                                                   \
+        if (px_ < 18 * 18) {                                                                             \
+            const int py_ = (px_ * 3641) >> 16;              /* px / 18, exact for px < 324 */            \
+            float* d_ = Rs + r_ch * W4_PLANE + py_ * W4_PITCH + (px_ - py_ * 18);                        \
+            d_[0] = raw[i].x; d_[W4_PLANE] = raw[i].y; d_[2 * W4_PLANE] = raw[i].z; d_[3 * W4_PLANE] = raw[i].w; \
+        }                                                                                                \
+    }
+#define CCVPE_W4_LOAD_B(wb, ks, qd)   /* k-step ks (global index), quad qd = xi 4qd .. 4qd+3 */           \
+    {                                                                                                    \
+        const f32x4 t4_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wb, (ks) * w_step_b + (qd) * w_quad_b, 0)); \
+        bq[4 * (qd)] = t4_.x; bq[4 * (qd) + 1] = t4_.y; bq[4 * (qd) + 2] = t4_.z; bq[4 * (qd) + 3] = t4_.w; \
+    }
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    CCVPE_W4_LOAD_RAW(g_begin * W4_GCH, 0);
+#pragma unroll
+    for (int qd = 0; qd < 9; ++qd) { CCVPE_W4_LOAD_B(w_base, g_begin * 4, qd); }
+    CCVPE_W4_STORE_RAW(0);
+    CCVPE_W4_LOAD_RAW(g_begin * W4_GCH, 1);
+    CCVPE_W4_STORE_RAW(1);
+    __syncthreads();
+
+    const float* va0 = Vs + lane * 2;
+    const bool split = p.splitk > 1;
+    const int ld = split ? p.N : p.dst[0].ld;
+    const int act = split ? ACT_NONE : p.act;
+
+    while (true) {
+        const int item_n = item + stride;
+        const bool have_n = item_n < item_end;
+        int nb_n, b_n, by_n, bx_n;
+        CCVPE_W4_DECODE(have_n ? item_n : item, nb_n, b_n, by_n, bx_n);
+        const unsigned w_base_n = have_n ? CCVPE_W4_WBASE(nb_n) : OOB;
+
+        for (int g = g_begin; g < g_end; ++g) {
+            const bool last_group = g == g_end - 1;
+            // ---- transform: B^T d B of this lane's (channel, tile), 36 values -> V image ----
+            // Two passes over the 6 x 6 patch, output rows 0-2 then 3-5 (18 live intermediates instead of 36); within a pass
+            // the column transform is software pipelined: column c + 1 is being read while column c is transformed.
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float t[3][6];
+                float dc[2][6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) dc[0][r] = t_src[r * W4_PITCH];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    if (c + 1 < 6) {
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) dc[(c + 1) & 1][r] = t_src[r * W4_PITCH + c + 1];
+                    }
+                    float u0, u1, u2, u3, u4, u5;
+                    w4_bt(dc[c & 1][0], dc[c & 1][1], dc[c & 1][2], dc[c & 1][3], dc[c & 1][4], dc[c & 1][5], u0, u1, u2, u3, u4, u5);
+                    t[0][c] = hf ? u3 : u0; t[1][c] = hf ? u4 : u1; t[2][c] = hf ? u5 : u2;
+                }
+#pragma unroll
+                for (int ii = 0; ii < 3; ++ii) {
+                    const int i = 3 * hf + ii;
+                    float v0, v1, v2, v3, v4, v5;
+                    w4_bt(t[ii][0], t[ii][1], t[ii][2], t[ii][3], t[ii][4], t[ii][5], v0, v1, v2, v3, v4, v5);
+                    // xi = 6*i + j; pairs (6i, 6i+1), (6i+2, 6i+3), (6i+4, 6i+5) = xp 3i .. 3i+2
+                    *reinterpret_cast<f32x2*>(t_dst + (3 * i + 0) * 128) = f32x2{v0, v1};
+                    *reinterpret_cast<f32x2*>(t_dst + (3 * i + 1) * 128) = f32x2{v2, v3};
+                    *reinterpret_cast<f32x2*>(t_dst + (3 * i + 2) * 128) = f32x2{v4, v5};
+                }
+            }
+            __syncthreads();   // V image complete; every wave is done with the raw patch
+            // ---- the patch after this one: next group of this tile, or the first group of the next tile ----
+            const int c0n = last_group ? g_begin * W4_GCH : (g + 1) * W4_GCH;
+            if (last_group) { CCVPE_W4_ROFF(b_n, by_n, bx_n, have_n); }
+            CCVPE_W4_LOAD_RAW(c0n, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA phase: 4 k-steps x 36 xi (a real loop: unrolled, hipcc renames the 144 accumulator and 36 weight
+            //      registers per k-step and spills a hundred of them) ----
+#pragma unroll 1
+            for (int ks = 0; ks < 4; ++ks) {
+                const bool last_step = last_group && ks == 3;
+                const unsigned wb = last_step ? w_base_n : w_base;
+                const int ksn = last_step ? g_begin * 4 : g * 4 + ks + 1;
+                const float* va = va0 + ks * (18 * 128);
+                f32x2 fa[2];
+                fa[0] = *reinterpret_cast<const f32x2*>(va);
+#pragma unroll
+                for (int xp = 0; xp < 18; ++xp) {
+                    if (xp + 1 < 18) fa[(xp + 1) & 1] = *reinterpret_cast<const f32x2*>(va + (xp + 1) * 128);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the next pair's read above this pair's MFMAs
+                    acc[2 * xp] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[xp & 1].x, bq[2 * xp], acc[2 * xp], 0, 0, 0);
+                    acc[2 * xp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[xp & 1].y, bq[2 * xp + 1], acc[2 * xp + 1], 0, 0, 0);
+                    if (xp & 1) {   // a quad's MFMAs have issued: refill its weight registers for the next k-step
+                        __builtin_amdgcn_sched_barrier(0);
+                        CCVPE_W4_LOAD_B(wb, ksn, xp >> 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 1) {   // first half of the next patch -> LDS (two k-steps of cover), second half into the same registers
+                    CCVPE_W4_STORE_RAW(0);
+                    CCVPE_W4_LOAD_RAW(c0n, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            CCVPE_W4_STORE_RAW(1);
+            __syncthreads();   // V image free again; next raw patch complete
+        }
+
+        // ---- inverse transform A^T M A, bias, activation, store ----
+        {
+            const int n = (nb * NW + wave) * 16 + (lane & 15);
+            const float bias = (split || n >= p.N) ? 0.f : p.bias[n];
+            const size_t pix0 = ((size_t)b * p.H + (size_t)by * 16) * p.W + (size_t)bx * 16;
+            float* obase = split ? p.partial + ((size_t)blockIdx.z * p.M + pix0) * p.N : p.dst[0].ptr + pix0 * ld + p.dst[0].coff;
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0x7fffffff, 0x00020000);
+            // lane part: tile row (lane >> 4) -> output rows 4*(lane>>4) .. +3, channel n; the (row, column) part is uniform
+            const unsigned o_lane = n < p.N ? (unsigned)((((lane >> 4) * 4 * p.W) * ld + n) * 4) : OOB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {          // tile column: accumulator element i of every xi
+                float tt[4][6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    w4_at(acc[0 * 6 + q][i], acc[1 * 6 + q][i], acc[2 * 6 + q][i], acc[3 * 6 + q][i], acc[4 * 6 + q][i], acc[5 * 6 + q][i],
+                          tt[0][q], tt[1][q], tt[2][q], tt[3][q]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    float y[4];
+                    w4_at(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], tt[a][5], y[0], y[1], y[2], y[3]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int soff = ((a * p.W + i * 4 + c) * ld) * 4;   // uniform
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(y[c] + bias, act)), o_rsrc, o_lane, soff, 0);
+                    }
+                }
+            }
+        }
+        if (!have_n) break;
+#pragma unroll
+        for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+        item = item_n; nb = nb_n; b = b_n; by = by_n; bx = bx_n; w_base = w_base_n;
+    }
+#undef CCVPE_W4_DECODE
+#undef CCVPE_W4_ROFF
+#undef CCVPE_W4_WBASE
+#undef CCVPE_W4_LOAD_RAW
+#undef CCVPE_W4_STORE_RAW
+#undef CCVPE_W4_LOAD_B
+}
+
+template <int NW>
+static void launch_wino4(const ConvParams& p, hipStream_t s) {
+    constexpr size_t lds = (W4_VFLOATS + W4_GCH * W4_PLANE) * sizeof(float);
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    static bool attr_done = false;
+    auto kern = conv_wino4_kernel<NW>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int mblocks = p.B * (p.W >> 4) * (p.H >> 4);
+    const int nblocks = (p.wino_n16 + NW - 1) / NW;
+    const int resident = 2 * 256 / (p.splitk > 1 ? p.splitk : 1);
+    dim3 grid(std::min(mblocks * nblocks, std::max(resident, 8)), 1, p.splitk > 1 ? p.splitk : 1);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+    if (p.splitk > 1) launch_splitk_reduce(p, s);
+}
+
+void launch_wino4_64(const ConvParams& p, hipStream_t s) { launch_wino4<4>(p, s); }
+
+bool conv_wino4_supported(const ConvParams& p) {
+    return p.wino4_w != nullptr && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.mode == MODE_CONV &&
+           p.gate == nullptr && p.resid == nullptr && p.ndst == 1 && !p.dst[0].split && !p.in_split && p.OH == p.H && p.OW == p.W &&
+           p.W % 16 == 0 && p.H % 16 == 0 && p.Cin % 8 == 0;
+}
+
+// Host-side weight transform: U = G g G^T (6 x 6) per (cout, cin) in double precision, stored as the B-fragment layout
+//   [k-step = cin/4][xi/4][n16][lane = (cin%4)*16 + cout%16][xi%4]       (1024 B per (k-step, quad, n16 slice))
+// with K padded to a multiple of 16 channels (zero weights).  `get(n, tap, c)` returns the 3x3 weight (tap = ky*3 + kx).
+size_t conv_wino4_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out) {
+    static const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const int n16 = (N + 15) / 16;
+    const int ksteps = ((cin + 15) / 16) * 4;
+    out.assign((size_t)ksteps * 9 * n16 * 256, 0.f);
+    auto work = [&](int n_lo, int n_hi) {
+        for (int n = n_lo; n < n_hi; ++n)
+            for (int c = 0; c < cin; ++c) {
+                double g[3][3], tmp[6][3];
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) g[i][j] = (double)get(n, i * 3 + j, c);
+                for (int r = 0; r < 6; ++r)
+                    for (int j = 0; j < 3; ++j) tmp[r][j] = G[r][0] * g[0][j] + G[r][1] * g[1][j] + G[r][2] * g[2][j];
+                const int ks = c / 4, k = c % 4;
+                for (int r = 0; r < 6; ++r)
+                    for (int q = 0; q < 6; ++q) {
+                        const double uv = tmp[r][0] * G[q][0] + tmp[r][1] * G[q][1] + tmp[r][2] * G[q][2];
+                        const int xi = r * 6 + q;
+                        const size_t idx = ((((size_t)ks * 9 + xi / 4) * n16 + n / 16) * 64 + k * 16 + (n % 16)) * 4 + (xi & 3);
+                        out[idx] = (float)uv;
+                    }
+            }
+    };
+    const int nthreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+    if (nthreads == 1 || (long long)N * cin < 4096) { work(0, N); return out.size(); }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back(work, (int)((long long)N * t / nthreads), (int)((long long)N * (t + 1) / nthreads));
+    for (auto& x : th) x.join();
+    return out.size();
+}
+
+}  // namespace ccvpe

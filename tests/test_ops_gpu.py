@@ -82,8 +82,8 @@ WINO_SHAPES = [
 
 @pytest.mark.parametrize("shape", WINO_SHAPES)
 def test_winograd_tiles_match_torch(shape):
-    """Winograd F(2x2,3x3) kernels (decoder double_conv, models.py:42-47): every NW variant, ragged Cout,
-    bias + ReLU epilogue, halo handling at all four image borders."""
+    """Winograd F(2x2,3x3) and F(4x4,3x3) kernels (decoder double_conv, models.py:42-47): every variant, ragged Cout,
+    bias + ReLU epilogue, halo handling at all four image borders, against an fp64 torch convolution."""
     lib = _lib.load()
     B, H, W, Cin, Cout = shape
     g = torch.Generator(device="cuda").manual_seed(sum(shape))
@@ -95,9 +95,37 @@ def test_winograd_tiles_match_torch(shape):
     for act in (0, 1):
         ref = ref_conv(x, w, b, 1, 1, act)
         for t in tiles:
+            name = lib.ccvpe_op_tile_name(t).decode()
+            f4 = "wino4" in name
+            if f4 and Cout < 64:      # F(4x4,3x3) weights are only packed for layers of >= 64 output channels
+                with pytest.raises(_lib.CcvpeError):
+                    _lib.op_conv2d(x, w, b, 1, 1, act, t)
+                continue
             out, _ = _lib.op_conv2d(x, w, b, 1, 1, act, t)
             err = (out - ref).abs().max().item() / ref.abs().max().item()
-            assert err <= 2e-5, f"tile {lib.ccvpe_op_tile_name(t).decode()} act {act}: {err:.3g}"
+            # F(2x2): transforms only add / subtract (measured 2-12e-7).  F(4x4): constants up to 8 amplify the fp32 rounding
+            # of the transforms (~1.4e-5 expected); both far inside the 1e-3 contract
+            assert err <= (1e-4 if f4 else 2e-5), f"tile {name} act {act}: {err:.3g}"
+
+
+@pytest.mark.parametrize("shape,splitk", [((2, 16, 16, 200, 160), 2), ((1, 32, 48, 104, 100), 4), ((3, 16, 16, 64, 88), 2)])
+def test_winograd_split_k(shape, splitk):
+    """Split-K form of the Winograd tiles (slab + reduce), incl. a K that does not divide into equal slices and the
+    16-channel group tail of the F(4x4,3x3) kernel (Cin = 200, 104)."""
+    lib = _lib.load()
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape) + splitk)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    ref = ref_conv(x, w, b, 1, 1, 1)
+    for t in range(1, lib.ccvpe_op_num_tiles() + 1):
+        name = lib.ccvpe_op_tile_name(t).decode()
+        if "wino" not in name:
+            continue
+        out, _ = _lib.op_conv2d(x, w, b, 1, 1, 1, t | (splitk << 8))
+        err = (out - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= (1e-4 if "wino4" in name else 2e-5), f"tile {name} split-K {splitk}: {err:.3g}"
 
 
 def test_conv2d_rejects_bad_geometry():
