@@ -100,6 +100,7 @@ bool conv_wino4_supported(const ConvParams& p);
 bool conv_wino_tile_supported(const ConvParams& p, int tile);   // the form tile id `tile` needs is packed and the layer is shaped for it
 bool conv_igemm_tile_is_wino4(int tile);
 void launch_wino4_64(const ConvParams& p, hipStream_t s);
+void launch_wino4_128(const ConvParams& p, hipStream_t s);
 size_t conv_wino4_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out);
 bool conv_igemm_tile_is_wino(int tile);
 size_t conv_wino_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out, int* n16_out);

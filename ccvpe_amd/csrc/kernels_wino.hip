@@ -331,7 +331,13 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
 }
 
 template <int NW, int NM, int GC>
-static void launch_wino(const ConvParams& p, hipStream_t s) {
+static void launch_wino(const ConvParams& p_in, hipStream_t s) {
+    ConvParams p = p_in;
+    if (p.splitk > 1) {   // never launch an empty K slice (it would leave its slab unwritten)
+        const int nch = p.Cin >> 3;
+        const int per = (nch + p.splitk - 1) / p.splitk;
+        p.splitk = (nch + per - 1) / per;
+    }
     constexpr size_t lds = (4096 * NM * (NM == 1 ? 2 : 1) + (8 * NM + 2) * 18 * (GC * 8 + 4)) * sizeof(float);
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     static bool attr_done = false;
@@ -358,6 +364,7 @@ static const WinoTile WINO_TILES[] = {
     {256, 48, "conv_wino_64x48", launch_wino<3, 2, 2>, 2},
     // F(4x4,3x3), kernels_wino4.hip: 16 tiles of 4x4 pixels x 64 channels per workgroup
     {256, 64, "conv_wino4_16x64", launch_wino4_64, 4},
+    {256, 128, "conv_wino4_16x128", launch_wino4_128, 4},
 };
 int wino_num_tiles() { return (int)(sizeof(WINO_TILES) / sizeof(WINO_TILES[0])); }
 const WinoTile* wino_tile(int i) { return &WINO_TILES[i]; }

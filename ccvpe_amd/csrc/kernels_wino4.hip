@@ -8,7 +8,9 @@
 // ~1.4e-5 of the output scale per layer against fp64 (F(2x2): 7e-7, implicit GEMM: 4e-7) - tests/test_ops_gpu.py
 // holds every tile to 1e-4, the path's contract is 1e-3.
 //
-// Work decomposition: a workgroup of 4 wave64 owns a 16 x 16 pixel block of one image (4 x 4 tiles = the 16 rows of
+// Work decomposition (NW = 4; the NW = 8 form doubles the channels per workgroup and halves the transform work per
+// output channel: 8 waves, one 512-thread workgroup per CU, each lane transforms half an item): a workgroup of 4 wave64
+// owns a 16 x 16 pixel block of one image (4 x 4 tiles = the 16 rows of
 // one v_mfma_f32_16x16x4_f32) x 64 output channels (16 per wave), for all 36 Winograd positions xi: 144 accumulator
 // registers per lane, so the inverse transform is a per-lane affair.  K is walked in groups of 16 input channels:
 //   * the raw 18 x 18 x 16 patch is staged channel-major in LDS (plane stride 385, row pitch 20: the 64 lanes of a
@@ -61,9 +63,11 @@ __device__ __forceinline__ void w4_at(const float m0, const float m1, const floa
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino4_kernel(const ConvParams p) {
-    static_assert(NW == 4, "one transform wave per k-step of a 16-channel group");
+    static_assert(NW == 4 || NW == 8, "waves w and w + 4 share the k-step w & 3 of a 16-channel group");
     constexpr int NT = NW * 64;
-    constexpr int RAW_ITEMS = (W4_RAW_F4 + NT - 1) / NT;   // 6
+    constexpr int RAW_ITEMS = NW == 4 ? 6 : 3;             // float4 items per thread of one raw group (1296 in all)
+    constexpr int RAW_HALVES = RAW_ITEMS / 3;              // staged three items at a time
+    constexpr int NPASS = 8 / NW;                          // transform half-items per lane: NW 4 -> both halves, NW 8 -> one
     constexpr unsigned OOB = 0x80000000u;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     //  LDS offset of an item is recomputed when it is stored and the patch travels in two halves of three float4)
     unsigned r_off[RAW_ITEMS];
     const int r_ch = (tid & 3) * 4;   // first channel inside the group (NT % 4 == 0: the same for every item of a thread)
-    const int r_px0 = tid >> 2;       // pixel of item 0; item i is pixel r_px0 + 64 i
+    const int r_px0 = tid >> 2;       // pixel of item 0; item i is pixel r_px0 + (NT / 4) i
 #define CCVPE_W4_ROFF(b_, by_, bx_, live_)                                                               \
     _Pragma("unroll") for (int i = 0; i < RAW_ITEMS; ++i) {                                              \
         const int j = tid + i * NT;                                                                      \
@@ -120,9 +124,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // ---- transform item of this lane: channel 4*wave + (lane & 3) of the group, tile (ty, tx) = (lane >> 4, (lane >> 2) & 3)
     const int tk = lane & 3, ttx = (lane >> 2) & 3, tty = lane >> 4;
-    const float* t_src = Rs + (4 * wave + tk) * W4_PLANE + (4 * tty) * W4_PITCH + 4 * ttx;
+    const int tks = wave & 3;         // k-step of the group this wave transforms (NW 8: waves w and w + 4 split its output rows)
+    const float* t_src = Rs + (4 * tks + tk) * W4_PLANE + (4 * tty) * W4_PITCH + 4 * ttx;
     // V position of the item = A-fragment lane (k * 16 + tile); xi pair xp lives 128 floats further per step
-    float* t_dst = Vs + ((wave * 18) * 64 + tk * 16 + tty * 4 + ttx) * 2;
+    float* t_dst = Vs + ((tks * 18) * 64 + tk * 16 + tty * 4 + ttx) * 2;
 
     // weights: [k-step][xi/4][n16 slice][lane][xi%4], one 16-byte load per (k-step, quad)
     const unsigned w_quad_b = (unsigned)p.wino_n16 * 1024u;      // bytes between consecutive quads
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
 #define CCVPE_W4_STORE_RAW(half)                                                                         \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                      \
-        const int px_ = r_px0 + 64 * (3 * (half) + i);                                                   \
+        const int px_ = r_px0 + (NT / 4) * (3 * (half) + i);                                             \
         if (px_ < 18 * 18) {                                                                             \
             const int py_ = (px_ * 3641) >> 16;              /* px / 18, exact for px < 324 */            \
             float* d_ = Rs + r_ch * W4_PLANE + py_ * W4_PITCH + (px_ - py_ * 18);                        \
@@ -171,8 +176,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
     for (int qd = 0; qd < 9; ++qd) { CCVPE_W4_LOAD_B(w_base, g_begin * 4, qd); }
     CCVPE_W4_STORE_RAW(0);
-    CCVPE_W4_LOAD_RAW(g_begin * W4_GCH, 1);
-    CCVPE_W4_STORE_RAW(1);
+    if (RAW_HALVES == 2) {
+        CCVPE_W4_LOAD_RAW(g_begin * W4_GCH, 1);
+        CCVPE_W4_STORE_RAW(1);
+    }
     __syncthreads();
 
     const float* va0 = Vs + lane * 2;
@@ -193,7 +200,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // Two passes over the 6 x 6 patch, output rows 0-2 then 3-5 (18 live intermediates instead of 36); within a pass
             // the column transform is software pipelined: column c + 1 is being read while column c is transformed.
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int hf = NW == 4 ? pass : (wave >> 2);   // output rows 3 hf .. 3 hf + 2 (uniform per wave)
                 float t[3][6];
                 float dc[2][6];
 #pragma unroll
@@ -206,17 +214,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     }
                     float u0, u1, u2, u3, u4, u5;
                     w4_bt(dc[c & 1][0], dc[c & 1][1], dc[c & 1][2], dc[c & 1][3], dc[c & 1][4], dc[c & 1][5], u0, u1, u2, u3, u4, u5);
-                    t[0][c] = hf ? u3 : u0; t[1][c] = hf ? u4 : u1; t[2][c] = hf ? u5 : u2;
+                    t[0][c] = hf ? u3 : u0; t[1][c] = hf ? u4 : u1; t[2][c] = hf ? u5 : u2;   // NW 8: hf is wave-uniform at run time
                 }
 #pragma unroll
                 for (int ii = 0; ii < 3; ++ii) {
-                    const int i = 3 * hf + ii;
                     float v0, v1, v2, v3, v4, v5;
                     w4_bt(t[ii][0], t[ii][1], t[ii][2], t[ii][3], t[ii][4], t[ii][5], v0, v1, v2, v3, v4, v5);
-                    // xi = 6*i + j; pairs (6i, 6i+1), (6i+2, 6i+3), (6i+4, 6i+5) = xp 3i .. 3i+2
-                    *reinterpret_cast<f32x2*>(t_dst + (3 * i + 0) * 128) = f32x2{v0, v1};
-                    *reinterpret_cast<f32x2*>(t_dst + (3 * i + 1) * 128) = f32x2{v2, v3};
-                    *reinterpret_cast<f32x2*>(t_dst + (3 * i + 2) * 128) = f32x2{v4, v5};
+                    // row i = 3 hf + ii; xi = 6 i + j; pairs (6i, 6i+1), (6i+2, 6i+3), (6i+4, 6i+5) = xp 3i .. 3i+2
+                    float* td = t_dst + hf * (9 * 128) + ii * (3 * 128);
+                    *reinterpret_cast<f32x2*>(td) = f32x2{v0, v1};
+                    *reinterpret_cast<f32x2*>(td + 128) = f32x2{v2, v3};
+                    *reinterpret_cast<f32x2*>(td + 256) = f32x2{v4, v5};
                 }
             }
             __syncthreads();   // V image complete; every wave is done with the raw patch
@@ -247,13 +255,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks == 1) {   // first half of the next patch -> LDS (two k-steps of cover), second half into the same registers
+                if (RAW_HALVES == 2 && ks == 1) {   // first half of the next patch -> LDS (two k-steps of cover), second half into the same registers
                     CCVPE_W4_STORE_RAW(0);
                     CCVPE_W4_LOAD_RAW(c0n, 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            CCVPE_W4_STORE_RAW(1);
+            CCVPE_W4_STORE_RAW(RAW_HALVES - 1);
             __syncthreads();   // V image free again; next raw patch complete
         }
 
@@ -299,7 +307,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 template <int NW>
-static void launch_wino4(const ConvParams& p, hipStream_t s) {
+static void launch_wino4(const ConvParams& p_in, hipStream_t s) {
+    ConvParams p = p_in;
+    if (p.splitk > 1) {   // never launch an empty K slice (it would leave its slab unwritten): 84 groups over 16 slices = 14 x 6
+        const int ngr = (p.Cin + W4_GCH - 1) / W4_GCH;
+        const int per = (ngr + p.splitk - 1) / p.splitk;
+        p.splitk = (ngr + per - 1) / per;
+    }
     constexpr size_t lds = (W4_VFLOATS + W4_GCH * W4_PLANE) * sizeof(float);
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     static bool attr_done = false;
@@ -310,13 +324,14 @@ static void launch_wino4(const ConvParams& p, hipStream_t s) {
     }
     const int mblocks = p.B * (p.W >> 4) * (p.H >> 4);
     const int nblocks = (p.wino_n16 + NW - 1) / NW;
-    const int resident = 2 * 256 / (p.splitk > 1 ? p.splitk : 1);
+    const int resident = (NW == 4 ? 2 : 1) * 256 / (p.splitk > 1 ? p.splitk : 1);   // 256-thread workgroups: two per CU, 512-thread: one
     dim3 grid(std::min(mblocks * nblocks, std::max(resident, 8)), 1, p.splitk > 1 ? p.splitk : 1);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
     if (p.splitk > 1) launch_splitk_reduce(p, s);
 }
 
 void launch_wino4_64(const ConvParams& p, hipStream_t s) { launch_wino4<4>(p, s); }
+void launch_wino4_128(const ConvParams& p, hipStream_t s) { launch_wino4<8>(p, s); }
 
 bool conv_wino4_supported(const ConvParams& p) {
     return p.wino4_w != nullptr && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.mode == MODE_CONV &&

@@ -108,7 +108,9 @@ def test_winograd_tiles_match_torch(shape):
             assert err <= (1e-4 if f4 else 2e-5), f"tile {name} act {act}: {err:.3g}"
 
 
-@pytest.mark.parametrize("shape,splitk", [((2, 16, 16, 200, 160), 2), ((1, 32, 48, 104, 100), 4), ((3, 16, 16, 64, 88), 2)])
+@pytest.mark.parametrize("shape,splitk", [((2, 16, 16, 200, 160), 2), ((1, 32, 48, 104, 100), 4), ((3, 16, 16, 64, 88), 2),
+                                          # more slices than equal shares fill: 5 / 3 groups of 16 channels, 10 / 5 chunks of 8 over 4 slices
+                                          ((1, 16, 16, 80, 64), 4), ((1, 16, 16, 40, 64), 4), ((2, 16, 16, 1344, 64), 16)])
 def test_winograd_split_k(shape, splitk):
     """Split-K form of the Winograd tiles (slab + reduce), incl. a K that does not divide into equal slices and the
     16-channel group tail of the F(4x4,3x3) kernel (Cin = 200, 104)."""
