@@ -35,6 +35,8 @@ SYMBOLS = [
     ("ccvpe_set_weight", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     ("ccvpe_skip_weight", C.c_int, [C.c_void_p, C.c_char_p]),
     ("ccvpe_finalize_weights", C.c_int, [C.c_void_p]),
+    ("ccvpe_save_packed", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("ccvpe_load_packed", C.c_int, [C.c_void_p, C.c_char_p]),
     ("ccvpe_max_micro_batch", C.c_int, [C.c_int32, C.c_float, C.c_int32, C.c_int32]),
     ("ccvpe_output_channels", C.c_int, [C.c_void_p, C.c_int32]),
     ("ccvpe_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),

@@ -52,6 +52,19 @@ def is_current() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile and link in-tree.  Several ranks of one node may import the package at once with a stale library: the
+    build runs under an exclusive file lock, objects and the library are written to temporary names and renamed into
+    place, so nobody ever dlopens a half-written file and only the first rank compiles."""
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     dig = _digest()
     if not force and is_current():
         return LIB
@@ -74,10 +87,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(f"hipcc failed on {src}:\n{out}", file=sys.stderr)
     if failed:
         raise RuntimeError("hipcc compilation failed")
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    tmp_lib = f"{LIB}.tmp.{os.getpid()}"
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp_lib, LIB)
     with open(STAMP, "w") as fh:
         fh.write(dig)
     return LIB

@@ -11,7 +11,9 @@ train_OxfordRobotCar.py:177-179) and reloads it with `CVM_model.load_state_dict(
   (nn.DataParallel) and a `{"state_dict": ...}` wrapper are accepted.
 
 Folding (BatchNorm into the convolutions), packing into the kernels' layouts and the upload happen at the next forward
-(`ccvpe_finalize_weights`); a packed-weight file cache is not built.
+(`ccvpe_finalize_weights`).  With a packed-weight cache directory (`weight_cache=` of the model constructor or the
+CCVPE_WEIGHT_CACHE environment variable) the packed device weights are written once, keyed by the content hash of the state
+dict, and later processes load them with `ccvpe_load_packed` instead of re-packing (ccvpe_amd/models.py `_cache_path`).
 """
 from __future__ import annotations
 

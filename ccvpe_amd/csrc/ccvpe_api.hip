@@ -18,6 +18,7 @@
 #include <memory>
 #include <set>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace ccvpe;
@@ -356,6 +357,7 @@ struct ccvpe_handle_s {
     bool two_streams = true;      // CCVPE_STREAMS=1 issues everything on the caller's stream
     bool serial_issue = false;    // ccvpe_set_streams(h, 1): run two-stream plans in program order on one stream
     std::vector<void*> dev_allocs;
+    std::vector<size_t> dev_alloc_bytes;   // parallel to dev_allocs (packed-weight cache: ccvpe_save_packed)
     EncoderW grd_enc, sat_enc;
     PackedConv grd_heads, sat_desc;
     float* grd_wh[6] = {nullptr};
@@ -435,6 +437,7 @@ static int upload(ccvpe_handle_s* h, const std::vector<float>& v, float** out) {
     size_t bytes = std::max<size_t>(v.size(), 4) * sizeof(float);
     HIPCHK(hipMalloc(&d, bytes));
     h->dev_allocs.push_back(d);
+    h->dev_alloc_bytes.push_back(bytes);
     HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
     *out = (float*)d;
     return 0;
@@ -483,6 +486,7 @@ static int pack_conv(ccvpe_handle_s* h, PackedConv& pc, int N, int taps, int cin
             void* d = nullptr;
             HIPCHK(hipMalloc(&d, hi.size() * sizeof(unsigned short)));
             h->dev_allocs.push_back(d);
+            h->dev_alloc_bytes.push_back(hi.size() * sizeof(unsigned short));
             HIPCHK(hipMemcpy(d, plane ? lo.data() : hi.data(), hi.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
             (plane ? pc.w_lo : pc.w_hi) = (unsigned short*)d;
         }
@@ -1122,6 +1126,26 @@ __global__ __launch_bounds__(256) void checksum_kernel(const uint32_t* __restric
     if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
+
+// ---- packed-weight cache --------------------------------------------------------------------------
+// ccvpe_finalize_weights folds BatchNorm, repacks ~60 M parameters into the kernels' layouts and runs the Winograd weight
+// transforms in double precision: seconds per handle.  Its result is a set of device buffers plus plain-data descriptor
+// structs that point into them.  ccvpe_save_packed writes both to a file; ccvpe_load_packed recreates the buffers and
+// re-bases every pointer of the descriptors (old device address -> new), so a later process skips the state_dict
+// ingestion and the packing entirely.  The caller keys the file (ccvpe_amd/models.py: sha256 of the state_dict bytes,
+// variant, precision, library build digest); the header carries variant / precision / struct sizes and is checked.
+struct PackedHeader {
+    char magic[8];                 // "CCVPEPK2"
+    int32_t variant, precision, circular, fuse_level1;
+    uint64_t n_allocs, sz_encoder, sz_decoder, sz_conv;
+};
+static void packed_state_io(ccvpe_handle_s* h, const std::function<void(void*, size_t)>& io) {
+    io(&h->grd_enc, sizeof(EncoderW)); io(&h->sat_enc, sizeof(EncoderW));
+    io(&h->grd_heads, sizeof(PackedConv)); io(&h->sat_desc, sizeof(PackedConv));
+    io(h->grd_wh, sizeof(h->grd_wh)); io(h->grd_b2, sizeof(h->grd_b2));
+    io(&h->loc, sizeof(DecoderW)); io(&h->ori, sizeof(DecoderW));
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -1238,6 +1262,7 @@ int ccvpe_finalize_weights(ccvpe_handle h) {
     // drop previous device copies (re-finalize after a new load_state_dict)
     for (void* p : h->dev_allocs) (void)hipFree(p);
     h->dev_allocs.clear();
+    h->dev_alloc_bytes.clear();
     h->plans.clear();
     h->last_plan = nullptr;
     int rc;
@@ -1276,6 +1301,79 @@ int ccvpe_finalize_weights(ccvpe_handle h) {
     return 0;
 }
 
+
+int ccvpe_save_packed(ccvpe_handle h, const char* path) {
+    if (!h || !path) return fail(CCVPE_EINVAL, "null argument");
+    if (!h->finalized) return fail(CCVPE_ESTATE, "ccvpe_finalize_weights has not been called");
+    static_assert(std::is_trivially_copyable<EncoderW>::value && std::is_trivially_copyable<DecoderW>::value && std::is_trivially_copyable<PackedConv>::value,
+                  "descriptor structs are written as plain bytes");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return fail(CCVPE_EINVAL, "cannot open %s for writing", tmp.c_str());
+    PackedHeader hd{};
+    std::memcpy(hd.magic, "CCVPEPK2", 8);
+    hd.variant = h->cfg.variant; hd.precision = h->cfg.reserved[0]; hd.circular = h->cfg.circular_padding; hd.fuse_level1 = h->fuse_level1 ? 1 : 0;
+    hd.n_allocs = h->dev_allocs.size(); hd.sz_encoder = sizeof(EncoderW); hd.sz_decoder = sizeof(DecoderW); hd.sz_conv = sizeof(PackedConv);
+    bool ok = std::fwrite(&hd, sizeof(hd), 1, f) == 1;
+    packed_state_io(h, [&](void* p, size_t n) { ok = ok && std::fwrite(p, 1, n, f) == n; });
+    std::vector<char> buf;
+    for (size_t i = 0; ok && i < h->dev_allocs.size(); ++i) {
+        const uint64_t old = (uint64_t)(uintptr_t)h->dev_allocs[i], bytes = h->dev_alloc_bytes[i];
+        buf.resize(bytes);
+        if (hipMemcpy(buf.data(), h->dev_allocs[i], bytes, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        ok = std::fwrite(&old, 8, 1, f) == 1 && std::fwrite(&bytes, 8, 1, f) == 1 && std::fwrite(buf.data(), 1, bytes, f) == bytes;
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok || std::rename(tmp.c_str(), path) != 0) { std::remove(tmp.c_str()); return fail(CCVPE_EINVAL, "writing %s failed", path); }
+    return 0;
+}
+
+int ccvpe_load_packed(ccvpe_handle h, const char* path) {
+    if (!h || !path) return fail(CCVPE_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(CCVPE_EINVAL, "cannot open %s", path);
+    PackedHeader hd{};
+    auto bad = [&](const char* why) { std::fclose(f); return fail(CCVPE_EINVAL, "%s: %s", path, why); };
+    if (std::fread(&hd, sizeof(hd), 1, f) != 1 || std::memcmp(hd.magic, "CCVPEPK2", 8) != 0) return bad("not a packed-weight file of this library version");
+    if (hd.variant != h->cfg.variant || hd.precision != h->cfg.reserved[0] || hd.circular != h->cfg.circular_padding) return bad("packed for a different variant / precision / padding mode");
+    if (hd.sz_encoder != sizeof(EncoderW) || hd.sz_decoder != sizeof(DecoderW) || hd.sz_conv != sizeof(PackedConv)) return bad("descriptor layout mismatch");
+    for (void* p : h->dev_allocs) (void)hipFree(p);
+    h->dev_allocs.clear(); h->dev_alloc_bytes.clear(); h->plans.clear(); h->last_plan = nullptr; h->finalized = false;
+    bool ok = true;
+    packed_state_io(h, [&](void* p, size_t n) { ok = ok && std::fread(p, 1, n, f) == n; });
+    std::map<uint64_t, uint64_t> remap;   // old device address -> new
+    std::vector<char> buf;
+    for (uint64_t i = 0; ok && i < hd.n_allocs; ++i) {
+        uint64_t old = 0, bytes = 0;
+        if (std::fread(&old, 8, 1, f) != 1 || std::fread(&bytes, 8, 1, f) != 1 || bytes > ((uint64_t)1 << 33)) { ok = false; break; }
+        buf.resize(bytes);
+        if (std::fread(buf.data(), 1, bytes, f) != bytes) { ok = false; break; }
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes) != hipSuccess) { ok = false; break; }
+        h->dev_allocs.push_back(d); h->dev_alloc_bytes.push_back(bytes);
+        if (hipMemcpy(d, buf.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { ok = false; break; }
+        remap[old] = (uint64_t)(uintptr_t)d;
+    }
+    std::fclose(f);
+    if (!ok) { g_err = std::string(path) + ": truncated or unreadable packed-weight file"; return CCVPE_EINVAL; }
+    // re-base the pointers: every 8-byte aligned word of the descriptor structs that equals an old buffer address
+    size_t patched = 0;
+    packed_state_io(h, [&](void* p, size_t n) {
+        uint64_t* w = reinterpret_cast<uint64_t*>(p);
+        for (size_t i = 0; i + 8 <= n; i += 8, ++w) {
+            auto it = remap.find(*w);
+            if (*w != 0 && it != remap.end()) { *w = it->second; ++patched; }
+        }
+    });
+    if (patched < hd.n_allocs / 2) return fail(CCVPE_EINVAL, "%s: descriptor / buffer table mismatch", path);
+    h->host.clear();
+    h->fuse_level1 = hd.fuse_level1 != 0 && h->fuse_level1;
+    h->finalized = true;
+    return 0;
+}
+
 int ccvpe_output_channels(ccvpe_handle h, int32_t level) {
     if (!h || level < 0 || level > 5) return fail(CCVPE_EINVAL, "bad level");
     return h->rolls[level];
@@ -1289,6 +1387,9 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
     c.arena = h->arena; c.off = &pl.off; c.stream = nullptr;
     c.splitk_scratch = c.ptr(pl.scratch); c.splitk_floats = Plan::SPLITK_FLOATS;
     if (pl.tune_cache.id >= 0) c.cache_out = c.ptr(pl.tune_cache);
+    // the candidates run on the null stream inside the shared arena: earlier forwards of this handle may still be in flight
+    // on a non-blocking caller stream or on the internal second stream (neither is ordered with the null stream)
+    HIPCHK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -1340,6 +1441,7 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    HIPCHK(hipDeviceSynchronize());   // ... and the forward that follows may be issued on such a stream
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(CCVPE_EHIP, "autotune launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -1803,6 +1905,7 @@ int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Ci
         void* d = nullptr;
         if (hipMalloc(&d, fl * sizeof(float)) != hipSuccess) { cleanup(); return fail(CCVPE_ENOMEM, "split-K slab"); }
         tmp.dev_allocs.push_back(d);
+        tmp.dev_alloc_bytes.push_back(fl * sizeof(float));
         p.partial = (float*)d; p.partial_floats = fl;
     }
     if (conv_igemm_tile_is_wino(tile) && !conv_wino_tile_supported(p, tile)) { cleanup(); return fail(CCVPE_EINVAL, "layer is not Winograd-shaped (3x3, stride 1, pad 1, W %% 16 == 0, H %% 16 == 0; F(4x4): >= 64 output channels)"); }

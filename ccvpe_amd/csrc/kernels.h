@@ -7,6 +7,17 @@
 
 namespace ccvpe {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: the launchers raise it lazily, once per
+// (kernel instantiation, device) - a process may hold handles on several devices.  `state` is a function-local static array
+// (one slot per device ordinal); a failing hipFuncSetAttribute leaves the slot unset, the launch that follows then fails and
+// the forward call reports it through hipGetLastError.
+struct LdsAttr { size_t set[16] = {0}; };
+inline void ensure_dynamic_lds(LdsAttr& state, const void* kernel, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (bytes > state.set[dev] && hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) state.set[dev] = bytes;
+}
+
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SWISH = 2 };
 
 // A destination view of an NHWC tensor: element (pixel p, channel c) lives at ptr[p*ld + coff + c].

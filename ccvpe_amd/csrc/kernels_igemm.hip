@@ -272,12 +272,9 @@ void launch_splitk_reduce(const ConvParams& p, hipStream_t s) {
 template <int BM, int BN, int WGM, int WGN, int MT, bool GATE, int NS>
 static void launch_cfg2(const ConvParams& p, hipStream_t s) {
     constexpr size_t lds = std::max<size_t>(NS * (BM + BN) * LDK, BM * (BN + 4)) * sizeof(float);   // stages | epilogue C tile
-    static bool attr_done = false;
+    static LdsAttr attr;
     auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, MT, GATE, NS>;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.splitk > 1 ? p.splitk : 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     if (p.splitk > 1) launch_splitk_reduce(p, s);

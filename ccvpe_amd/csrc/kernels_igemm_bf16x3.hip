@@ -358,12 +358,9 @@ static void launch_b2(const ConvParams& p, hipStream_t s) {
     constexpr size_t stage_bytes = 2 * (size_t)(2 * BM + 2 * BN) * 64;
     constexpr size_t c_bytes = (size_t)BM * (BN + 4) * sizeof(float);
     constexpr size_t lds = stage_bytes > c_bytes ? stage_bytes : c_bytes;
-    static bool attr_done = false;
+    static LdsAttr attr;
     auto kern = conv_igemm_bf16x3_kernel<BM, BN, WGM, WGN, MT, GATE, SPLIT>;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.splitk > 1 ? p.splitk : 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     if (p.splitk > 1) launch_splitk_reduce(p, s);

@@ -283,12 +283,12 @@ void launch_level1(const Level1Params& p, hipStream_t s) {
     const int tiles = (p.W / T) * (p.H / T) * p.B;
     dim3 grid(std::min(tiles, 2 * 256));   // persistent: two workgroups per CU
     if (p.cout == 1) {
-        static size_t set1 = 0;
-        if (lds > set1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(level1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set1 = lds; }
+        static LdsAttr attr1;
+        ensure_dynamic_lds(attr1, reinterpret_cast<const void*>(level1_kernel<1>), lds);
         hipLaunchKernelGGL(level1_kernel<1>, grid, dim3(256), lds, s, p);
     } else {
-        static size_t set2 = 0;
-        if (lds > set2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(level1_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set2 = lds; }
+        static LdsAttr attr2;
+        ensure_dynamic_lds(attr2, reinterpret_cast<const void*>(level1_kernel<2>), lds);
         hipLaunchKernelGGL(level1_kernel<2>, grid, dim3(256), lds, s, p);
     }
 }

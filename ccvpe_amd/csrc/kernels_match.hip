@@ -209,11 +209,8 @@ void launch_match(const MatchParams& p, hipStream_t s) {
         return;
     }
     size_t lds = ((size_t)p.P * (p.C + 1) + ((p.L + 3) & ~3) + (size_t)(p.R + 1) * p.P + 4) * sizeof(float);
-    static size_t max_set = 0;
-    if (lds > 64 * 1024 && lds > max_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        max_set = lds;
-    }
+    static LdsAttr attr;
+    if (lds > 64 * 1024) ensure_dynamic_lds(attr, reinterpret_cast<const void*>(match_kernel), lds);
     hipLaunchKernelGGL(match_kernel, dim3(p.B * (p.HW / p.P)), dim3(256), lds, s, p);
 }
 

@@ -171,9 +171,9 @@ static void launch_mb(const MbFrontParams& p, hipStream_t s) {
     constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K, NIP = IW * IH;
     const int XS = p.cinp + 4;
     const size_t lds = ((size_t)NIP * XS + (size_t)MC * XS + (size_t)NIP * ES + 16 * MC) * sizeof(float) + ((NIP + 15) & ~15);
-    static size_t set = 0;
+    static LdsAttr attr;
     auto kern = mbconv_front_kernel<K, S, TW, TH>;
-    if (lds > set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = lds; }
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     const int tiles = ((p.OW + TW - 1) / TW) * ((p.OH + TH - 1) / TH);
     hipLaunchKernelGGL(kern, dim3(tiles, p.B), dim3(256), lds, s, p);
 }

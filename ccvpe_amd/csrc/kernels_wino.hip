@@ -340,12 +340,9 @@ static void launch_wino(const ConvParams& p_in, hipStream_t s) {
     }
     constexpr size_t lds = (4096 * NM * (NM == 1 ? 2 : 1) + (8 * NM + 2) * 18 * (GC * 8 + 4)) * sizeof(float);
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    static bool attr_done = false;
+    static LdsAttr attr;
     auto kern = conv_wino_kernel<NW, NM, GC>;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     const int mblocks = p.B * (p.W >> 4) * (p.H / (8 * NM));
     const int nblocks = (p.wino_n16 + NW - 1) / NW;
     // persistent grid: two workgroups per CU (the register budget allows no more) loop over the tiles

@@ -316,12 +316,9 @@ static void launch_wino4(const ConvParams& p_in, hipStream_t s) {
     }
     constexpr size_t lds = (W4_VFLOATS + W4_GCH * W4_PLANE) * sizeof(float);
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    static bool attr_done = false;
+    static LdsAttr attr;
     auto kern = conv_wino4_kernel<NW>;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     const int mblocks = p.B * (p.W >> 4) * (p.H >> 4);
     const int nblocks = (p.wino_n16 + NW - 1) / NW;
     const int resident = (NW == 4 ? 2 : 1) * 256 / (p.splitk > 1 ? p.splitk : 1);   // 256-thread workgroups: two per CU, 512-thread: one

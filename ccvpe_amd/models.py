@@ -12,6 +12,7 @@ Inference only: no autograd through the HIP path, `eval()` mode required, GPU re
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -74,7 +75,7 @@ class _CVMBase(nn.Module):
     _variant: str = ""
 
     def __init__(self, device, circular_padding: bool = False, ori_noise: Optional[float] = None,
-                 micro_batch: int = 0, precision: str = "fp32"):
+                 micro_batch: int = 0, precision: str = "fp32", weight_cache: Optional[str] = None):
         super().__init__()
         v = spec.VARIANTS[self._variant]
         self.device = device
@@ -84,6 +85,9 @@ class _CVMBase(nn.Module):
         if precision not in ("fp32", "bf16x3"):
             raise ValueError("precision must be 'fp32' (exact fp32 MFMA) or 'bf16x3' (3-term bf16 split, ~1e-5 relative)")
         self._precision = precision
+        # packed-weight cache directory: None = environment CCVPE_WEIGHT_CACHE, empty = off
+        self._weight_cache = weight_cache if weight_cache is not None else os.environ.get("CCVPE_WEIGHT_CACHE", "")
+        self.last_weight_source = None   # "packed-cache" or "state_dict" after the first forward (introspection / tests)
 
         self.grd_efficientnet = _EfficientNetParams()
         for lvl, c in enumerate(v.head_ch, 1):
@@ -154,18 +158,46 @@ class _CVMBase(nn.Module):
             if getattr(self, "_n_streams", 2) != 2:
                 _lib.check(lib.ccvpe_set_streams(h, self._n_streams), "ccvpe_set_streams")
         if self._weights_dirty:
-            for key, t in self.state_dict().items():
-                if t.dtype != torch.float32 or "._fc." in key:
-                    _lib.check(lib.ccvpe_skip_weight(self._handle, key.encode()), f"ccvpe_skip_weight({key})")
-                    continue
-                t = t.detach().contiguous()
-                shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
-                _lib.check(lib.ccvpe_set_weight(self._handle, key.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()),
-                           f"ccvpe_set_weight({key})")
-            if dev.type == "cuda":
-                torch.cuda.synchronize(dev)
-            _lib.check(lib.ccvpe_finalize_weights(self._handle), "ccvpe_finalize_weights")
+            sd = self.state_dict()
+            cache_file = self._cache_path(sd) if self._weight_cache else None
+            if cache_file and os.path.exists(cache_file) and lib.ccvpe_load_packed(self._handle, cache_file.encode()) == 0:
+                self.last_weight_source = "packed-cache"
+            else:
+                for key, t in sd.items():
+                    if t.dtype != torch.float32 or "._fc." in key:
+                        _lib.check(lib.ccvpe_skip_weight(self._handle, key.encode()), f"ccvpe_skip_weight({key})")
+                        continue
+                    t = t.detach().contiguous()
+                    shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+                    _lib.check(lib.ccvpe_set_weight(self._handle, key.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()),
+                               f"ccvpe_set_weight({key})")
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+                _lib.check(lib.ccvpe_finalize_weights(self._handle), "ccvpe_finalize_weights")
+                self.last_weight_source = "state_dict"
+                if cache_file:
+                    os.makedirs(os.path.dirname(cache_file), exist_ok=True)
+                    _lib.check(lib.ccvpe_save_packed(self._handle, cache_file.encode()), "ccvpe_save_packed")
             self._weights_dirty = False
+
+    def _cache_path(self, sd) -> str:
+        """File name of the packed weights of this exact state dict: content hash of every float tensor in key order,
+        variant, precision, padding mode and the digest of the library sources (a rebuilt library repacks)."""
+        import hashlib
+        try:
+            import xxhash
+            hsh = xxhash.xxh3_128()
+        except ImportError:
+            hsh = hashlib.sha256()
+        for key in sorted(sd):
+            t = sd[key]
+            if t.dtype != torch.float32 or "._fc." in key:
+                continue
+            hsh.update(key.encode())
+            hsh.update(t.detach().cpu().contiguous().numpy().tobytes())
+        from . import build as _build
+        tag = f"{self._variant}-{self._precision}-{int(self.circular_padding)}-{_build._digest()[:16]}-{hsh.hexdigest()[:32]}"
+        return os.path.join(self._weight_cache, tag + ".ccvpepack")
 
     # ---- forward ----------------------------------------------------------------------------
     def _prepare(self, grd: torch.Tensor, sat: torch.Tensor):

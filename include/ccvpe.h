@@ -111,6 +111,14 @@ int ccvpe_skip_weight(ccvpe_handle h, const char* key);
  * uploads it.  Fails with CCVPE_EKEY (message lists the first missing key) if any key is unset. */
 int ccvpe_finalize_weights(ccvpe_handle h);
 
+/* Packed-weight cache (reference train_VIGOR.py:252 reloads and, here, re-packs the checkpoint on every start): after
+ * ccvpe_finalize_weights, ccvpe_save_packed writes the folded / repacked / Winograd-transformed device weights to `path`;
+ * in a later process ccvpe_load_packed(h, path) on a handle created with the same config replaces the 818 ccvpe_set_weight
+ * calls and ccvpe_finalize_weights.  The caller keys the file by the checkpoint's content (see ccvpe_amd/models.py).
+ * CCVPE_EINVAL if the file is missing, truncated, or was packed for another variant / precision / library build. */
+int ccvpe_save_packed(ccvpe_handle h, const char* path);
+int ccvpe_load_packed(ccvpe_handle h, const char* path);
+
 /* Largest micro_batch whose intermediate tensors all stay below the 2 GiB the kernels address with 32-bit byte offsets
  * (ccvpe_forward refuses a larger one with CCVPE_EINVAL instead of wrapping offsets).  Pure host arithmetic, no device
  * needed.  Negative on a ground size the variant's descriptor heads cannot take. */

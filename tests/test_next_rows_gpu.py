@@ -163,3 +163,44 @@ def test_ground_truth_side_metrics_match_the_restated_test_loop():
     ref = orc.eval_metrics(heat.cpu().numpy(), ori.cpu().numpy(), gt_index, 0.113248 / 512 * 640, gt_cs)
     assert torch.isnan(got["lateral_m"]).all()
     assert np.allclose(got["meter_distance"].cpu().numpy(), ref["meter_distance"], rtol=1e-12)
+
+
+def test_packed_weight_cache_round_trip(tmp_path):
+    """the folded / repacked / Winograd-transformed device weights are written once and loaded by a later
+    handle instead of re-packing the checkpoint; outputs are bit-identical, a different state dict gets its own file, and a
+    corrupt file falls back to the state dict."""
+    import os
+    cfg = gu.CONFIGS["oxford"]
+    sd = weights.generate_state_dict("oxford", 5)
+    g, s = weights.generate_inputs("oxford", 1, 5)
+    g, s = torch.from_numpy(g).cuda(), torch.from_numpy(s).cuda()
+
+    def make(sdict):
+        m = models.CVM_OxfordRobotCar("cuda", weight_cache=str(tmp_path))
+        m.load_state_dict(sdict)
+        return m.to("cuda").eval()
+
+    a = make(sd)
+    ref = [o.clone() for o in a(g, s)]
+    assert a.last_weight_source == "state_dict"
+    files = sorted(os.listdir(tmp_path))
+    assert len(files) == 1 and files[0].endswith(".ccvpepack")
+    b = make(sd)
+    outs = b(g, s)
+    assert b.last_weight_source == "packed-cache"
+    # same packed bits; per-layer tiles are re-tuned per handle, so allow the noise of a different tile / Winograd form
+    # (the unit orientation field, index 2, amplifies it where the raw vector is tiny: covered by the parity tests)
+    for i, (x, y) in enumerate(zip(ref, outs)):
+        if i != 2:
+            assert (x - y).abs().max().item() <= 1e-4 * max(x.abs().max().item(), 1e-30), gu.OUTPUT_NAMES[i]
+    c = make(weights.generate_state_dict("oxford", 6))          # other weights -> other key, not the cached file
+    c(g, s)
+    assert c.last_weight_source == "state_dict" and len(os.listdir(tmp_path)) == 2
+    with open(os.path.join(tmp_path, files[0]), "r+b") as fh:   # truncate: the loader must refuse, the model re-packs
+        fh.truncate(4096)
+    d = make(sd)
+    outs = d(g, s)
+    assert d.last_weight_source == "state_dict"
+    for i, (x, y) in enumerate(zip(ref, outs)):
+        if i != 2:
+            assert (x - y).abs().max().item() <= 1e-4 * max(x.abs().max().item(), 1e-30), gu.OUTPUT_NAMES[i]
