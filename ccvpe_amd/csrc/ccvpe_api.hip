@@ -461,9 +461,11 @@ static int pack_conv(ccvpe_handle_s* h, PackedConv& pc, int N, int taps, int cin
         conv_wino_pack(N, cin, get, u, &pc.wino_n16);
         pc.wino_bytes = u.size() * sizeof(float);
         if ((rc = upload(h, u, &pc.wino))) return rc;
-        // F(4x4,3x3) pays where the layer is matrix-pipe bound and fills 64-channel slices: >= 64 output channels
-        // (4x the direct weights: ~0.5 GB for the layers that qualify)
-        if (N >= 64 && (size_t)((cin + 15) / 16) * 4 * 9 * ((N + 15) / 16) * 1024 < (1u << 31) && !getenv("CCVPE_NO_WINO4")) {
+        // F(4x4,3x3) pays where the layer fills at least three of a workgroup's four 16-channel slices: measured faster than
+        // every F(2x2) tile down to 40 output channels (conv2: 0.52 vs 0.64 ms), slower at 32 (conv2_ori: 0.41 vs 0.37);
+        // 4x the direct weights, ~0.5 GB for the layers that qualify
+        static const int wino4_min_n = getenv("CCVPE_WINO4_MIN_N") ? std::atoi(getenv("CCVPE_WINO4_MIN_N")) : 40;
+        if (N >= wino4_min_n && (size_t)((cin + 15) / 16) * 4 * 9 * ((N + 15) / 16) * 1024 < (1u << 31) && !getenv("CCVPE_NO_WINO4")) {
             std::vector<float> u4;
             conv_wino4_pack(N, cin, get, u4);
             pc.wino4_bytes = u4.size() * sizeof(float);
@@ -1908,7 +1910,7 @@ int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Ci
         tmp.dev_alloc_bytes.push_back(fl * sizeof(float));
         p.partial = (float*)d; p.partial_floats = fl;
     }
-    if (conv_igemm_tile_is_wino(tile) && !conv_wino_tile_supported(p, tile)) { cleanup(); return fail(CCVPE_EINVAL, "layer is not Winograd-shaped (3x3, stride 1, pad 1, W %% 16 == 0, H %% 16 == 0; F(4x4): >= 64 output channels)"); }
+    if (conv_igemm_tile_is_wino(tile) && !conv_wino_tile_supported(p, tile)) { cleanup(); return fail(CCVPE_EINVAL, "layer is not Winograd-shaped (3x3, stride 1, pad 1, W %% 16 == 0, H %% 16 == 0; F(4x4): >= 40 output channels)"); }
     if (launch_conv_igemm(p, tile, st) != 0) { cleanup(); return fail(CCVPE_EINVAL, "unsupported conv geometry (KH*KW <= 16, Cin %% 8 == 0)"); }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && iters > 0 && ms) {

@@ -97,7 +97,7 @@ def test_winograd_tiles_match_torch(shape):
         for t in tiles:
             name = lib.ccvpe_op_tile_name(t).decode()
             f4 = "wino4" in name
-            if f4 and Cout < 64:      # F(4x4,3x3) weights are only packed for layers of >= 64 output channels
+            if f4 and Cout < 40:      # F(4x4,3x3) weights are only packed for layers of >= 40 output channels
                 with pytest.raises(_lib.CcvpeError):
                     _lib.op_conv2d(x, w, b, 1, 1, act, t)
                 continue
