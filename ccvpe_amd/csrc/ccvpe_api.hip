@@ -1008,7 +1008,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
         mp.cat_max_ld = 8 + C;
         mp.cat_all_ld = rpad + C;
         Tensor xin = x, lin = loc_in[k];
-        Tensor ggs = pl.alloc(B, 1, 1, 4 * C + 4);
+        Tensor ggs = pl.alloc(B, 1, 1, (int)match_scratch_floats(C));
         const bool first = (k == 0);
         const int goff = loff[k];
         const int R = mp.R;

@@ -210,10 +210,11 @@ struct MatchParams {
     // ori concat buffer: ch0..R-1 = scores, zero pad to rpad, then normalised x
     float* cat_all;  int cat_all_ld;  int rpad;
     int P;                     // pixels per block (power of two, divides HW)
-    float* gg_scratch;         // [B][4C+4] scratch for the small-C register form (null = LDS form only)
+    float* gg_scratch;         // [B][match_scratch_floats(C)]: rolled descriptor of the small-C register form / Gm, Mk of the MFMA form (null = LDS form only)
 };
 void launch_match(const MatchParams& p, hipStream_t s);
 int match_pixels_per_block(int HW, int C);
+size_t match_scratch_floats(int C);   // per-sample floats of MatchParams::gg_scratch
 
 // ---------------------------------------------------------------------------------------------
 // Tail: 16 -> {1,2} 3x3 conv to NCHW (+ unit-normalise for ori), softmax, post-processing

@@ -12,6 +12,8 @@
 // [max | 7 zero pad | x/||x||] and optionally (c) the orientation concat buffer [scores | pad | x/||x||].
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace ccvpe {
 
 __global__ __launch_bounds__(256) void match_kernel(const MatchParams p) {
@@ -188,6 +190,157 @@ __global__ __launch_bounds__(256) void match_small_kernel(const MatchParams p, c
         *reinterpret_cast<float4*>(o + 8 + c4 * 4) = make_float4(x[c4 * 4] * inv, x[c4 * 4 + 1] * inv, x[c4 * 4 + 2] * inv, x[c4 * 4 + 3] * inv);
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA form for the wide levels (C >= 128; models.py:485-511 with C = 1280 .. 160, KITTI 2048 .. 128): the (pixel, roll)
+// dot products of match_kernel are one contraction  S[p][r] = sum_j x[p][j] * Gm[j][r],  Gm[j][r] = g[(j - s_r) mod C] inside the
+// window (0 outside), and the window norms are  N2[p][r] = sum_j x[p][j]^2 * Mk[j][r]  with the 0/1 window mask; column 31 of Mk is
+// all ones (the full-vector norm F.normalize needs).  match_kernel evaluates them with two LDS reads per FMA and is LDS-bound
+// (1.2 TB/s on levels 1-4); here a workgroup stages 16 pixels x C channels once (x is still read from HBM exactly once), its four
+// waves split C between them, each k-step of 16 channels is one ds_read_b128 of x feeding 8 v_mfma_f32_16x16x4_f32 (2 roll tiles x
+// {x, x^2}... 16 with the norms), and the partial sums meet in LDS.  Gm / Mk are built per sample by match_mfma_prep_kernel in
+// B-fragment order [16-channel chunk][roll tile][lane][4] (one 16-byte load per lane and chunk).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void match_mfma_prep_kernel(const MatchParams p, float* gm) {
+    // gm[b]: [C/16 chunks][2 tiles][64 lanes][4] for G, then the same for the mask, then ||g||
+    __shared__ float red[4];
+    const int b = blockIdx.x, C = p.C, L = p.L;
+    const size_t per = (size_t)C * 32;
+    float* G = gm + (size_t)b * (2 * per + 4);
+    float* M = G + per;
+    const float* g = p.g + (size_t)b * p.g_ld;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < C * 32; i += gridDim.y * 256) {
+        const int e = i & 3, lane = (i >> 2) & 63, t = (i >> 8) & 1, chunk = i >> 9;
+        const int j = chunk * 16 + 4 * (lane >> 4) + e;       // input channel (k index of the fragment)
+        const int r = t * 16 + (lane & 15);                   // roll column
+        float gv = 0.f, mv = 0.f;
+        if (r < p.R) {
+            int c = j - p.shift[r];
+            if (c < 0) c += C;
+            if (c < L) { gv = g[c]; mv = 1.f; }
+        } else if (r == 31) {
+            mv = 1.f;
+        }
+        G[i] = gv; M[i] = mv;
+    }
+    if (blockIdx.y != 0) return;
+    float gsq = 0.f;
+    for (int i = threadIdx.x; i < L; i += 256) gsq = fmaf(g[i], g[i], gsq);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gsq += __shfl_xor(gsq, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gsq;
+    __syncthreads();
+    if (threadIdx.x == 0) G[2 * per] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void match_mfma_kernel(const MatchParams p, const float* __restrict__ gm) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int C = p.C, R = p.R;
+    const int ldx = C + 4;                 // 16-byte rows, 4 mod 32 floats (C % 32 == 0): conflict-free b128 reads across the 16 pixels
+    float* xs = smem;                      // [16][C + 4]
+    float* red = xs + 16 * ldx;            // [4 waves][2 (S, N2)][2 tiles][64 lanes][4]
+    float* sc = red + 4 * 2 * 2 * 256;     // [32][16] final scores (row 31: squared full norm)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blocks_per_sample = p.HW >> 4;
+    const int b = blockIdx.x / blocks_per_sample;
+    const int pix0 = (blockIdx.x - b * blocks_per_sample) << 4;
+    const float* xg = p.x + ((size_t)b * p.HW + pix0) * p.x_ld;
+
+    const int c4n = C >> 2;
+    for (int i = tid; i < 16 * c4n; i += 256) {
+        const int pp = i / c4n, c4 = i - pp * c4n;
+        *reinterpret_cast<f32x4m*>(xs + pp * ldx + c4 * 4) = *reinterpret_cast<const f32x4m*>(xg + (size_t)pp * p.x_ld + c4 * 4);
+    }
+    __syncthreads();
+
+    const size_t per = (size_t)C * 32;
+    const float* G = gm + (size_t)b * (2 * per + 4);
+    const float* M = G + per;
+    const float gnorm = G[2 * per];
+    // wave w owns chunks w, w + 4, ... of 16 channels
+    f32x4m accS[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accN[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const float* ap = xs + (lane & 15) * ldx + 4 * (lane >> 4);
+    const int nchunks = C >> 4;
+    for (int ch = wave; ch < nchunks; ch += 4) {
+        const f32x4m a = *reinterpret_cast<const f32x4m*>(ap + ch * 16);
+        const f32x4m a2 = a * a;
+        const f32x4m g0 = *reinterpret_cast<const f32x4m*>(G + ((size_t)(ch * 2 + 0) * 64 + lane) * 4);
+        const f32x4m g1 = *reinterpret_cast<const f32x4m*>(G + ((size_t)(ch * 2 + 1) * 64 + lane) * 4);
+        const f32x4m m0 = *reinterpret_cast<const f32x4m*>(M + ((size_t)(ch * 2 + 0) * 64 + lane) * 4);
+        const f32x4m m1 = *reinterpret_cast<const f32x4m*>(M + ((size_t)(ch * 2 + 1) * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            accS[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], g0[e], accS[0], 0, 0, 0);
+            accS[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], g1[e], accS[1], 0, 0, 0);
+            accN[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[e], m0[e], accN[0], 0, 0, 0);
+            accN[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[e], m1[e], accN[1], 0, 0, 0);
+        }
+    }
+    // partial sums -> LDS; accumulator element i of lane l is (pixel 4*(l>>4) + i, roll 16*t + (l&15))
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        *reinterpret_cast<f32x4m*>(red + (((wave * 2 + 0) * 2 + t) * 64 + lane) * 4) = accS[t];
+        *reinterpret_cast<f32x4m*>(red + (((wave * 2 + 1) * 2 + t) * 64 + lane) * 4) = accN[t];
+    }
+    __syncthreads();
+    {   // thread = (tile t, lane l, element i) of the 2 x 64 x 4 = 512 (pixel, roll) sums: two per thread
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = tid + k * 256;
+            const int t = idx >> 8, l = (idx >> 2) & 63, i = idx & 3;
+            float s = 0.f, n2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s += red[(((w * 2 + 0) * 2 + t) * 64 + l) * 4 + i];
+                n2 += red[(((w * 2 + 1) * 2 + t) * 64 + l) * 4 + i];
+            }
+            const int pp = 4 * (l >> 4) + i, r = 16 * t + (l & 15);
+            sc[r * 16 + pp] = r == 31 ? n2 : s / (sqrtf(n2) * gnorm);     // no epsilon, as models.py:494
+        }
+    }
+    __syncthreads();
+
+    if (p.ms) {
+        for (int it = tid; it < 16 * R; it += 256) {
+            const int pp = it & 15, r = it >> 4;
+            p.ms[((size_t)b * R + r) * p.HW + pix0 + pp] = sc[r * 16 + pp];
+        }
+    }
+    if (p.cat_max) {
+        for (int it = tid; it < 16 * 8; it += 256) {
+            const int pp = it >> 3, ch = it & 7;
+            float v = 0.f;
+            if (ch == 0) {
+                v = -INFINITY;
+                for (int r = 0; r < R; ++r)
+                    if ((p.inmax >> r) & 1u) v = fmaxf(v, sc[r * 16 + pp]);
+            }
+            p.cat_max[((size_t)b * p.HW + pix0 + pp) * p.cat_max_ld + ch] = v;
+        }
+    }
+    if (p.cat_all) {
+        for (int it = tid; it < 16 * p.rpad; it += 256) {
+            const int pp = it / p.rpad, ch = it - pp * p.rpad;
+            p.cat_all[((size_t)b * p.HW + pix0 + pp) * p.cat_all_ld + ch] = ch < R ? sc[ch * 16 + pp] : 0.f;
+        }
+    }
+    for (int i = tid; i < 16 * c4n; i += 256) {
+        const int pp = i / c4n, c4 = i - pp * c4n;
+        const float inv = 1.f / fmaxf(sqrtf(sc[31 * 16 + pp]), 1e-12f);
+        const f32x4m v = *reinterpret_cast<const f32x4m*>(xs + pp * ldx + c4 * 4) * inv;
+        const size_t pix = (size_t)b * p.HW + pix0 + pp;
+        if (p.cat_max) *reinterpret_cast<f32x4m*>(p.cat_max + pix * p.cat_max_ld + 8 + c4 * 4) = v;
+        if (p.cat_all) *reinterpret_cast<f32x4m*>(p.cat_all + pix * p.cat_all_ld + p.rpad + c4 * 4) = v;
+    }
+}
+
+bool match_mfma_supported(const MatchParams& p) {
+    return p.gg_scratch != nullptr && p.C >= 128 && p.C % 32 == 0 && p.C <= 2048 && p.R <= 31 && p.HW % 16 == 0 && p.x_ld % 4 == 0 &&
+           (p.cat_max == nullptr || p.cat_max_ld % 4 == 0) && (p.cat_all == nullptr || (p.cat_all_ld % 4 == 0 && p.rpad % 4 == 0));
+}
+size_t match_scratch_floats(int C) { return C >= 128 ? (size_t)2 * C * 32 + 4 : (size_t)4 * C + 4; }
+
 bool match_small_supported(const MatchParams& p) {
     return (p.C == 32 || p.C == 40 || p.C == 80) && p.cat_all == nullptr && p.cat_max != nullptr && p.x_ld % 4 == 0;
 }
@@ -200,6 +353,15 @@ int match_pixels_per_block(int HW, int C) {
 }
 
 void launch_match(const MatchParams& p, hipStream_t s) {
+    static const bool no_mfma = getenv("CCVPE_MATCH_MFMA") && std::atoi(getenv("CCVPE_MATCH_MFMA")) == 0;
+    if (!no_mfma && match_mfma_supported(p)) {
+        hipLaunchKernelGGL(match_mfma_prep_kernel, dim3(p.B, 8), dim3(256), 0, s, p, p.gg_scratch);
+        const size_t lds = ((size_t)16 * (p.C + 4) + 4 * 2 * 2 * 256 + 32 * 16) * sizeof(float);
+        static LdsAttr attr;
+        if (lds > 64 * 1024) ensure_dynamic_lds(attr, reinterpret_cast<const void*>(match_mfma_kernel), lds);
+        hipLaunchKernelGGL(match_mfma_kernel, dim3(p.B * (p.HW >> 4)), dim3(256), lds, s, p, (const float*)p.gg_scratch);
+        return;
+    }
     if (p.gg_scratch && match_small_supported(p)) {
         hipLaunchKernelGGL(match_prep_kernel, dim3(p.B), dim3(256), 0, s, p, p.gg_scratch);
         dim3 grid((p.HW + 255) / 256, p.B);
