@@ -8,7 +8,9 @@
 
 namespace ccvpe {
 
-__device__ __forceinline__ float swishf(float v) { return v / (1.f + __expf(-v)); }
+// x * sigmoid(x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division: the division expands to ~10
+// instructions (v_div_scale / v_div_fmas / v_div_fixup + Newton steps) per activation, and the encoder applies ~10^9 of them
+__device__ __forceinline__ float swishf(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
 // ------------------------------------------------------------------------------------------------
 // Stem: 3x3 stride 2, 3 -> 32 channels, NCHW input -> NHWC output, BN + swish.

@@ -15,6 +15,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace ccvpe {
 
@@ -23,7 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int MC = 48;          // expanded channels per chunk (96, 144, 240 are multiples of 48)
 static constexpr int ES = MC + 4;      // floats per pixel in the E tile (208 B: conflict-free b128)
 
-__device__ __forceinline__ float swish_f(float v) { return __fdividef(v, 1.f + __expf(-v)); }
+__device__ __forceinline__ float swish_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }   // v_rcp_f32, not an IEEE division
 
 // TW x TH output tile; input tile IW x IH = ((TW-1)*S + K) x ((TH-1)*S + K)
 template <int K, int S, int TW, int TH>
@@ -166,6 +167,149 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-local form (round 2).  The kernel above runs three workgroup barriers per 48-channel chunk of a 32-pixel tile and
+// measured 7x off its HBM roofline (block 1 of the aerial encoder: 0.41 ms for 335 MB).  Here ONE WAVE owns an output tile
+// for all expanded channels: it stages its input tile (+ halo) in its own LDS region, then per chunk of 16 expanded channels
+// runs the expand GEMM on v_mfma_f32_16x16x4_f32 into its own E tile, the depthwise conv from that tile, the store and the
+// pooling partial - nothing but s_waitcnt between the stages, no barrier anywhere, eight single-wave workgroups per CU.
+// Same tile shapes as above, so the pooling partial layout [B][tiles][mid] is unchanged.
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr int ES2 = 20;        // floats per pixel of the 16-channel E tile (conflict-free epilogue writes and b128 reads)
+
+template <int K, int S, int TW, int TH, int KCH>
+__global__ __launch_bounds__(64, KCH == 1 ? 3 : 2) void mbconv_front_wave_kernel(const MbFrontParams p) {
+    constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K;
+    constexpr int NIP = IW * IH;
+    constexpr int NMT = (NIP + 15) / 16;
+    constexpr int NOP = TW * TH;
+    constexpr int OPL = NOP / 16;            // outputs per lane slot (2 for 8x4, 4 for 8x8)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CP = KCH * 16;             // input channels padded to 16
+    float* Es = smem;                        // [NMT * 16][ES2] (rows >= NIP: sink of the last m-tile's padding rows)
+
+    const int lane = threadIdx.x;
+    const int tiles_x = (p.OW + TW - 1) / TW;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
+
+    // ---- input tile straight into the MFMA A-operand registers: lane (l & 15, l >> 4) holds channels 16 kc + 4 (l >> 4) .. + 3
+    // of pixel 16 mt + (l & 15) for every m-tile (zero outside the image; horizontal wrap for circular layers).  No LDS
+    // copy of the input: the E tile is the only LDS the wave needs (12.8 KB -> twelve waves per CU).
+    f32x4 xa[NMT][KCH];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+        const int px = min(mt * 16 + (lane & 15), NIP - 1);
+        const int iy = iy0 + px / IW;
+        int ix = ix0 + px % IW;
+        bool ok = (unsigned)iy < (unsigned)p.H;
+        if (p.circular) { if (ix < 0) ix += p.W; else if (ix >= p.W) ix -= p.W; }
+        ok = ok && (unsigned)ix < (unsigned)p.W;
+        const float* src = p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.Cin + 4 * (lane >> 4);
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+            const int c = kc * 16 + 4 * (lane >> 4);
+            xa[mt][kc] = (ok && c < p.Cin) ? *reinterpret_cast<const f32x4*>(src + kc * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // validity of the 4 * NMT pixels this lane's accumulator rows cover (the reference zero-pads the EXPANDED activation)
+    unsigned vmask[(NMT + 7) / 8] = {0};     // bit (mt % 8) * 4 + r of word mt / 8
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int px = mt * 16 + (lane >> 4) * 4 + r;
+            const int iy = iy0 + px / IW;
+            int ix = ix0 + px % IW;
+            if (p.circular) { if (ix < 0) ix += p.W; else if (ix >= p.W) ix -= p.W; }
+            const bool ok = px < NIP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            vmask[mt >> 3] |= (ok ? 1u : 0u) << ((mt & 7) * 4 + r);
+        }
+    const int q = lane & 3, slot = lane >> 2;    // depthwise: channel quad q of the chunk, output slot (16 slots x OPL outputs)
+    for (int ch0 = 0; ch0 < p.mid; ch0 += 16) {
+        // ---- expand: E[px][n] = swish(sum_c X[px][c] We[ch0 + n][c] + be) for the NIP input pixels ----
+        f32x4 wfrag[KCH];                        // B fragments: We[ch0 + (lane & 15)][16 kc + 4 (lane >> 4) + e]
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc)
+            wfrag[kc] = *reinterpret_cast<const f32x4*>(p.we + (size_t)(ch0 + (lane & 15)) * CP + kc * 16 + 4 * (lane >> 4));
+        const float be = p.be[ch0 + (lane & 15)];
+        // four m-tiles at a time: four independent accumulator chains hide the 40-cycle dependent-MFMA latency
+#pragma unroll
+        for (int mt0 = 0; mt0 < NMT; mt0 += 4) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (mt0 + u < NMT) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[mt0 + u][kc][e], wfrag[kc][e], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int mt = mt0 + u;
+                if (mt >= NMT) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int px = mt * 16 + (lane >> 4) * 4 + r;          // rows >= NIP land in the sink rows
+                    const float keep = (float)((vmask[mt >> 3] >> ((mt & 7) * 4 + r)) & 1u);   // a multiply, not a branch around the swish
+                    Es[px * ES2 + (lane & 15)] = swish_f(acc[u][r] + be) * keep;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        // ---- depthwise K x K from the E tile, BN + swish, store, pooling partial ----
+        const int c = ch0 + q * 4;
+        const f32x4 bd = *reinterpret_cast<const f32x4*>(p.bd + c);
+        f32x4 wk[K * K];
+#pragma unroll
+        for (int t = 0; t < K * K; ++t) wk[t] = *reinterpret_cast<const f32x4*>(p.wd + (size_t)t * p.mid + c);
+        f32x4 pool = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < OPL; ++i) {
+            const int o = slot + 16 * i;
+            const int oyl = o / TW, oxl = o - oyl * TW;
+            const float* ep = Es + ((oyl * S) * IW + oxl * S) * ES2 + q * 4;
+            f32x4 acc = bd;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) acc += *reinterpret_cast<const f32x4*>(ep + (ky * IW + kx) * ES2) * wk[ky * K + kx];
+            const int oy = oy0 + oyl, ox = ox0 + oxl;
+            if (oy < p.OH && ox < p.OW) {
+                f32x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = swish_f(acc[e]);
+                pool += ov;
+                *reinterpret_cast<f32x4*>(p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.mid + c) = ov;
+            }
+        }
+        // sum over the 16 slots (lanes with equal q): xor-shuffles over lane bits 2..5; fixed order -> deterministic
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pool[e] += __shfl_xor(pool[e], off);
+        if (slot == 0) *reinterpret_cast<f32x4*>(p.pool + ((size_t)b * gridDim.x + tile) * p.mid + c) = pool;
+        __builtin_amdgcn_s_waitcnt(0);       // the E tile is rewritten by the next chunk's expand
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int K, int S, int TW, int TH, int KCH>
+static void launch_mb_wave(const MbFrontParams& p, hipStream_t s) {
+    constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K, NIP = IW * IH;
+    const size_t lds = (size_t)((NIP + 15) / 16 * 16) * ES2 * sizeof(float);
+    static LdsAttr attr;
+    auto kern = mbconv_front_wave_kernel<K, S, TW, TH, KCH>;
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
+    const int tiles = ((p.OW + TW - 1) / TW) * ((p.OH + TH - 1) / TH);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.B), dim3(64), lds, s, p);
+}
+
 template <int K, int S, int TW, int TH>
 static void launch_mb(const MbFrontParams& p, hipStream_t s) {
     constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K, NIP = IW * IH;
@@ -199,6 +343,13 @@ bool mbconv_front_supported(int k, int s, int cin, int mid) {
 bool mbconv_front_profitable(int k) { return k == 3; }
 
 void launch_mbconv_front(const MbFrontParams& p, hipStream_t s) {
+    static const bool wave_form = getenv("CCVPE_MBCONV_WAVE") && std::atoi(getenv("CCVPE_MBCONV_WAVE")) != 0;   // opt-in until it measures faster
+    if (wave_form && p.k == 3 && p.cinp <= 48 && p.cinp % 16 == 0 && p.mid % 16 == 0) {
+        const int kch = p.cinp / 16;
+        if (p.s == 1) { if (kch == 1) launch_mb_wave<3, 1, 8, 8, 1>(p, s); else if (kch == 2) launch_mb_wave<3, 1, 8, 8, 2>(p, s); else launch_mb_wave<3, 1, 8, 8, 3>(p, s); }
+        else { if (kch == 1) launch_mb_wave<3, 2, 8, 4, 1>(p, s); else if (kch == 2) launch_mb_wave<3, 2, 8, 4, 2>(p, s); else launch_mb_wave<3, 2, 8, 4, 3>(p, s); }
+        return;
+    }
     if (p.k == 3 && p.s == 1) launch_mb<3, 1, 8, 8>(p, s);
     else if (p.k == 3 && p.s == 2) launch_mb<3, 2, 8, 4>(p, s);
     else if (p.k == 5 && p.s == 1) launch_mb<5, 1, 8, 8>(p, s);
