@@ -184,6 +184,7 @@ struct Op {
     bool bf16x3_only = false;     // the launch reads a pre-split bf16 tensor: exact-fp32 tiles cannot serve it
     bool wino_ok = false;         // 3x3 / stride 1 layer with Winograd-domain weights packed
     bool wino4_ok = false;        // ... with the F(4x4,3x3) weights packed as well
+    bool is_pw = false;           // 1x1 conv / k2s2 transposed conv: the pointwise persistent tiles may serve it
     // two-stream execution (Plan::schedule): stream the op is issued on, ops of the other stream it must wait for,
     // and whether an op of the other stream waits for this one (then an event is recorded after it)
     int stream = 0;
@@ -723,6 +724,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
                 p.dst[0] = {c.ptr(e), mid, 0}; p.ndst = 1;
                 c.launch_conv(p, tile);
             }, 2.0 * B * ch * cw * b.cin * mid, 4.0 * B * ch * cw * (b.cin + mid));
+            pl.ops.back().is_pw = true;
         }
         {
             DwParams dp{};
@@ -764,6 +766,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
                 for (int t = 0; t < td.n; ++t) p.dst[p.ndst++] = c.dst(td.t[t], td.coff[t]);
                 c.launch_conv(p, tile);
             }, 2.0 * B * oh * ow * mid * b.cout, 4.0 * B * oh * ow * (mid + b.cout * (1 + td.n)));
+            pl.ops.back().is_pw = true;
         }
         out.tap[i] = o;
         pl.taps[tag + "_block" + std::to_string(i)] = {o, 0, o.C};
@@ -779,6 +782,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
             p.dst[0] = {c.ptr(vol), 1280, 0}; p.ndst = 1;
             c.launch_conv(p, tile);
         }, 2.0 * B * ch * cw * 320 * 1280, 4.0 * B * ch * cw * 1600);
+        pl.ops.back().is_pw = true;
     }
     out.vol = vol;
     pl.taps[tag + "_volume"] = {vol, 0, 1280};
@@ -929,6 +933,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
                 p.dst[0] = c.dst(cat); p.ndst = 1;
                 c.launch_conv(p, tile);
             }, 2.0 * B * hin * hin * (double)l.din * 4 * l.dout, 4.0 * B * hin * hin * ((double)din.C + 4.0 * l.dout));
+            pl.ops.back().is_pw = !din.split;
         }
         Tensor mid = pl.alloc(B, hout, hout, l.mid);
         mid.split = cat.split;   // bf16x3 mode: conv_a -> conv_b hand-off stays in split bf16 form
@@ -1412,9 +1417,17 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
             if (op.bf16x3_only && !conv_igemm_tile_is_bf16x3(t)) continue;
             if (conv_igemm_tile_is_wino(t) && !op.wino_ok) continue;
             if (conv_igemm_tile_is_wino4(t) && !op.wino4_ok) continue;
+            static const bool prefer_pw = getenv("CCVPE_TUNE_PREFER_PW") != nullptr;   // test hook: pointwise tiles wherever they apply
+            if (prefer_pw && op.is_pw && !op.bf16x3_only && !conv_igemm_tile_is_pw(t) && op.gemm_kpad <= 512) continue;
+            if (conv_igemm_tile_is_pw(t)) {
+                ConvParams qq{}; qq.M = 16; qq.N = 1 << 20;
+                const int bn = (int)(((long long)qq.N) / conv_igemm_tile_blocks(qq, t));   // the tile's column width
+                if (!op.is_pw || op.bf16x3_only || !conv_pw_fits(bn, op.gemm_kpad) || getenv("CCVPE_NO_PW")) continue;
+            }
             const long long blocks = conv_igemm_tile_blocks(q, t);
             static const bool no_split = getenv("CCVPE_TUNE_SPLITK") && std::atoi(getenv("CCVPE_TUNE_SPLITK")) == 0;
             for (int split = 1; split <= (no_split ? 1 : 16); split *= 2) {
+                if (split > 1 && conv_igemm_tile_is_pw(t)) break;   // the pointwise persistent tiles keep K whole
                 if (split > 1) {   // split-K only where the grid underfills the chip and K is deep enough
                     // (the persistent Winograd grid also splits when the tile count is an awkward multiple of the
                     // 512 resident workgroups: 640 tiles = 1.25 per workgroup, 4 x 640 quarter-tiles = 5 each)

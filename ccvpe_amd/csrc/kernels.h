@@ -115,6 +115,13 @@ void launch_wino4_128(const ConvParams& p, hipStream_t s);
 size_t conv_wino4_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out);
 bool conv_igemm_tile_is_wino(int tile);
 size_t conv_wino_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out, int* n16_out);
+// pointwise persistent kernel (kernels_pw.hip): 1x1 convs / k2s2 transposed convs with K <= 512
+struct PwTile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); };
+int pw_num_tiles();
+const PwTile* pw_tile(int i);
+bool conv_pw_supported(const ConvParams& p);
+bool conv_pw_fits(int bn, int kpad);
+bool conv_igemm_tile_is_pw(int tile);
 int conv_igemm_last_tile();  // tile id of the most recent launch on this thread (then reset to 0)
 const char* conv_igemm_tile_name(int tile);
 

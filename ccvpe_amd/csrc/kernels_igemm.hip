@@ -319,8 +319,10 @@ static const TileCfg TILES[] = {
 static constexpr int NTILES = (int)(sizeof(TILES) / sizeof(TILES[0]));
 
 int conv_igemm_npad() { return 128; }
-int conv_igemm_num_tiles() { return NTILES + bf16x3_num_tiles() + wino_num_tiles(); }
-bool conv_igemm_tile_is_wino(int tile) { tile &= 0xff; return tile > NTILES + bf16x3_num_tiles() && tile <= conv_igemm_num_tiles(); }
+int conv_igemm_num_tiles() { return NTILES + bf16x3_num_tiles() + wino_num_tiles() + pw_num_tiles(); }
+bool conv_igemm_tile_is_wino(int tile) { tile &= 0xff; return tile > NTILES + bf16x3_num_tiles() && tile <= NTILES + bf16x3_num_tiles() + wino_num_tiles(); }
+static int pw_index(int tile) { return (tile & 0xff) - NTILES - bf16x3_num_tiles() - wino_num_tiles() - 1; }
+bool conv_igemm_tile_is_pw(int tile) { const int i = pw_index(tile); return i >= 0 && i < pw_num_tiles(); }
 bool conv_igemm_tile_is_wino4(int tile) { return conv_igemm_tile_is_wino(tile) && wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->f == 4; }
 bool conv_wino_tile_supported(const ConvParams& p, int tile) {
     if (!conv_igemm_tile_is_wino(tile)) return false;
@@ -331,6 +333,7 @@ static void tile_dims(int tile, int& bm, int& bn) {
     if (tile >= 1 && tile <= NTILES) { bm = TILES[tile - 1].bm; bn = TILES[tile - 1].bn; }
     else if (conv_igemm_tile_is_bf16x3(tile)) { bm = (*bf16x3_tile(tile - NTILES - 1)).bm; bn = (*bf16x3_tile(tile - NTILES - 1)).bn; }
     else if (conv_igemm_tile_is_wino(tile)) { bm = wino_tile(tile - NTILES - bf16x3_num_tiles() - 1)->bm; bn = wino_tile(tile - NTILES - bf16x3_num_tiles() - 1)->bn; }
+    else if (conv_igemm_tile_is_pw(tile)) { bm = pw_tile(pw_index(tile))->bm; bn = pw_tile(pw_index(tile))->bn; }
     else { bm = bn = 0; }
 }
 
@@ -374,6 +377,7 @@ const char* conv_igemm_tile_name(int tile) {
     if (tile >= 1 && tile <= NTILES) return TILES[tile - 1].name;
     if (conv_igemm_tile_is_bf16x3(tile)) return (*bf16x3_tile(tile - NTILES - 1)).name;
     if (conv_igemm_tile_is_wino(tile)) return wino_tile(tile - NTILES - bf16x3_num_tiles() - 1)->name;
+    if (conv_igemm_tile_is_pw(tile)) return pw_tile(pw_index(tile))->name;
     return "";
 }
 
@@ -448,7 +452,9 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
     int splitk = (tile >> 8) & 0xff;
     tile &= 0xff;
     if (conv_igemm_tile_is_bf16x3(tile) && (p.w_hi == nullptr || p.w_lo == nullptr)) tile = 0;   // planes not packed: fp32 path
-    if (conv_igemm_tile_is_wino(tile) && !conv_wino_tile_supported(p, tile)) tile = 0;   // not a Winograd-shaped layer: implicit GEMM
+    if (conv_igemm_tile_is_wino(tile) && !conv_wino_tile_supported(p, tile)) tile = 0;
+    if (conv_igemm_tile_is_pw(tile) && !(conv_pw_supported(p) && conv_pw_fits(pw_tile(pw_index(tile))->bn, p.Kpad))) tile = 0;   // not a shallow 1x1 layer
+    if (conv_igemm_tile_is_pw(tile)) splitk = 1;   // not a Winograd-shaped layer: implicit GEMM
     if (tile < 1 || tile > conv_igemm_num_tiles()) tile = pick_tile(p);
     if (p.in_split) {   // pre-split bf16 input: only the bf16x3 kernels can read it
         if (p.w_hi == nullptr) return -1;
@@ -458,6 +464,7 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
     p.splitk = splitk;
     g_last_tile = tile | (splitk << 8);
     if (tile <= NTILES) TILES[tile - 1].launch(p, s);
+    else if (conv_igemm_tile_is_pw(tile)) pw_tile(pw_index(tile))->launch(p, s);
     else if (conv_igemm_tile_is_wino(tile)) wino_tile(tile - NTILES - bf16x3_num_tiles() - 1)->launch(p, s);
     else (*bf16x3_tile(tile - NTILES - 1)).launch(p, s);
     return 0;

@@ -130,6 +130,32 @@ def test_winograd_split_k(shape, splitk):
         assert err <= (1e-4 if "wino4" in name else 2e-5), f"tile {name} split-K {splitk}: {err:.3g}"
 
 
+PW_SHAPES = [
+    # B, H, W, Cin, Cout: 1x1 layers of the encoders (expand / project / head shapes, ragged M and N, K tails)
+    (2, 16, 16, 16, 96), (1, 19, 23, 40, 240), (3, 8, 8, 112, 672), (2, 16, 16, 480, 80), (1, 16, 16, 24, 144), (2, 5, 7, 328, 40),
+]
+
+
+@pytest.mark.parametrize("shape", PW_SHAPES)
+def test_pointwise_persistent_tiles_match_torch(shape):
+    """conv_pw_kernel (1x1 convs with K <= 512 straight from HBM into the MFMA operand registers): every column width,
+    swish / none epilogues, rows and columns that do not fill the last tile, K that is not a multiple of 16."""
+    lib = _lib.load()
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, device="cuda", generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    tiles = [t for t in range(1, lib.ccvpe_op_num_tiles() + 1) if b"conv_pw" in lib.ccvpe_op_tile_name(t)]
+    assert len(tiles) >= 4
+    for act in (0, 2):
+        ref = ref_conv(x, w, b, 1, 0, act)
+        for t in tiles:
+            out, _ = _lib.op_conv2d(x, w, b, 1, 0, act, t)
+            err = (out - ref).abs().max().item() / ref.abs().max().item()
+            assert err <= 2e-5, f"tile {lib.ccvpe_op_tile_name(t).decode()} act {act}: {err:.3g}"
+
+
 def test_conv2d_rejects_bad_geometry():
     x = torch.randn(1, 4, 4, 12, device="cuda")
     w = torch.randn(4, 12, 1, 1, device="cuda")

@@ -217,3 +217,16 @@ def test_two_stream_schedule_is_bitwise_identical_to_program_order(name, batch, 
         results.append([o.clone() for o in outs])
     for a, b, c in zip(*results):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("name", ["vigor_prior180_circ", "kitti"])
+def test_pointwise_persistent_tiles_everywhere_match_golden(name, monkeypatch):
+    """CCVPE_TUNE_PREFER_PW routes every 1x1 layer with K <= 512 (expand, gated project with residual and concat taps,
+    head, transposed convs with the pixel-shuffle epilogue) through conv_pw_kernel, whatever the autotuner would pick."""
+    monkeypatch.setenv("CCVPE_TUNE_PREFER_PW", "1")
+    cfg = gu.CONFIGS[name]
+    fx = gu.load(name)
+    m = build_model(cfg)
+    g, s = inputs(cfg)
+    worst = check_against_fixture(fx, m(g, s), RTOL)
+    assert worst <= CONTRACT_RTOL
