@@ -33,7 +33,7 @@ def run_pair(B, lag_ms):
     ma, mb = build(), build()
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     ga, sa_in = g[:B].contiguous(), s[:B].contiguous()
-    gb, sb_in = g[B:2*B].contiguous(), s[B:2*B].contiguous()
+    gb, sb_in = (g[B:2*B].contiguous(), s[B:2*B].contiguous()) if 2 * B <= g.shape[0] else (ga.clone(), sa_in.clone())
     for _ in range(5):
         with torch.cuda.stream(sa): ma(ga, sa_in)
         with torch.cuda.stream(sb): mb(gb, sb_in)
@@ -56,3 +56,5 @@ run_single(16)
 run_pair(16, 0)
 run_pair(16, 4)
 run_pair(8, 2)
+run_pair(32, 0)
+run_pair(32, 7)
