@@ -24,7 +24,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # (tools/repro_pk_mfma.hip).  The match kernels share the chip with the bf16x3 decoder kernels of the
 # other stream, so they are built without SLP packing (same instruction count: the packed form needed v_mov pairs).
 # tests/test_isa_hazard.py checks the generated ISA of every kernel for that encoding.
-EXTRA_FLAGS = {"kernels_match.hip": ["-fno-slp-vectorize"]}
+# kernels_wino4.hip: the SLP vectoriser packs the Winograd transforms into v_pk_fma_f32 / v_pk_add_f32 plus ~50 v_mov_b32 per
+# pass to pair the operands; beside fp32 MFMAs every vector instruction costs issue time (tools/ubench_fill.hip), so the scalar
+# form (fewer instructions, no moves) is the faster one.
+EXTRA_FLAGS = {"kernels_match.hip": ["-fno-slp-vectorize"], "kernels_wino4.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

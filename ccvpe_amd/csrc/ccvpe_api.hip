@@ -139,6 +139,7 @@ struct EncoderW {
 struct DecoderW {
     PackedConv deconv[6], conva[6], convb[5];
     float* tail_w = nullptr;
+    float* l1_wt = nullptr;       // the same weights as [9][cout][16] for the fused level-1 kernel (channel pairs contiguous)
     float tail_b[2] = {0.f, 0.f};
     // fused last level (kernels_level1.hip)
     float *l1_wd = nullptr, *l1_bd = nullptr, *l1_wa = nullptr, *l1_ba = nullptr;
@@ -636,6 +637,11 @@ static int build_decoder(ccvpe_handle_s* h, DecoderW& d, const DecLevel* lv, con
                 for (int c = 0; c < 16; ++c)
                     for (int t = 0; t < 9; ++t) pk[(t * 16 + c) * cout + o] = w2[((size_t)o * 16 + c) * 9 + t];
             if ((rc = upload(h, pk, &d.tail_w))) return rc;
+            std::vector<float> pk1(9 * 16 * cout);
+            for (int o = 0; o < cout; ++o)
+                for (int c = 0; c < 16; ++c)
+                    for (int t = 0; t < 9; ++t) pk1[(t * cout + o) * 16 + c] = w2[((size_t)o * 16 + c) * 9 + t];
+            if ((rc = upload(h, pk1, &d.l1_wt))) return rc;
             for (int o = 0; o < cout; ++o) d.tail_b[o] = b2[o];
         }
     }
@@ -972,7 +978,7 @@ static int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mo
     auto plan_level1_fused = [&](const DecoderW& dw, Tensor din, int cin_real, int cout, bool is_ori, Tensor raw, const std::string& tag) {
         Level1Params lp{};
         lp.x_ld = din.C; lp.cx = dw.l1_cx; lp.cxp = dw.l1_cxp; lp.B = B; lp.H = CCVPE_OUT_HW; lp.W = CCVPE_OUT_HW;
-        lp.wd = dw.l1_wd; lp.bd = dw.l1_bd; lp.wa = dw.l1_wa; lp.ba = dw.l1_ba; lp.wt = dw.tail_w;
+        lp.wd = dw.l1_wd; lp.bd = dw.l1_bd; lp.wa = dw.l1_wa; lp.ba = dw.l1_ba; lp.wt = dw.l1_wt;
         lp.bt[0] = dw.tail_b[0]; lp.bt[1] = dw.tail_b[1]; lp.cout = cout; lp.normalize = is_ori ? 1 : 0;
         const bool has_raw = raw.id >= 0;
         std::vector<Tensor> uses = {din};

@@ -248,7 +248,7 @@ struct Level1Params {
     const float* bd;           // [16]
     const float* wa;           // [16][144]  k = (ky*3+kx)*16 + c
     const float* ba;           // [16]
-    const float* wt;           // [9][16][cout]
+    const float* wt;           // [9][cout][16]
     float bt[2];
     int cout, normalize;
     float* out;                // NCHW [B, cout, H, W]

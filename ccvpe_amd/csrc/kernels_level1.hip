@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
     for (int t = 0; t < 9; ++t) wa[t] = *reinterpret_cast<const f32x4*>(p.wa + (size_t)(lane & 15) * 144 + t * 16 + 4 * (lane >> 4));
     const float bd = p.bd[lane & 15];
     const float ba = p.ba[lane & 15];
-    const float* __restrict__ wt = p.wt;   // [9][16][COUT], uniform -> scalar loads
+    const float* __restrict__ wt = p.wt;   // [9][COUT][16], uniform -> scalar loads; a channel pair is one aligned SGPR pair
 
     // X tile staging: float4 item i = tid + it*256 -> pixel i / c4n, channels 4*(i % c4n)
     const int c4n = CXP >> 2;
@@ -237,9 +237,9 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(ap + c4 * 4);
 #pragma unroll
                 for (int c = 0; c < COUT; ++c) {
-                    const float* wp = wt + (t * 16 + c4 * 4) * COUT + c;
-                    o2[c] = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{wp[0], wp[COUT]}, o2[c]);
-                    o2[c] = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{wp[2 * COUT], wp[3 * COUT]}, o2[c]);
+                    const float* wp = wt + (t * COUT + c) * 16 + c4 * 4;
+                    o2[c] = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{wp[0], wp[1]}, o2[c]);
+                    o2[c] = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{wp[2], wp[3]}, o2[c]);
                 }
             }
         }

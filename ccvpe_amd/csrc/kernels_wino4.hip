@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <thread>
+#include <type_traits>
 
 namespace ccvpe {
 
@@ -67,7 +68,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int NT = NW * 64;
     constexpr int RAW_ITEMS = NW == 4 ? 6 : 3;             // float4 items per thread of one raw group (1296 in all)
     constexpr int RAW_HALVES = RAW_ITEMS / 3;              // staged three items at a time
-    constexpr int NPASS = 8 / NW;                          // transform half-items per lane: NW 4 -> both halves, NW 8 -> one
     constexpr unsigned OOB = 0x80000000u;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -149,12 +149,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     float bq[36];             // B fragments of the current k-step, refilled in place for the next one
     // channels past Cin (last group of a layer whose Cin is not a multiple of 16) are forced to zero
 #define CCVPE_W4_LOAD_RAW(c0, half)   /* items 3*half .. 3*half+2 */                                     \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                      \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                    \
         const unsigned o_ = ((c0) + r_ch < p.Cin) ? r_off[3 * (half) + i] : OOB;                         \
         raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, o_, (c0) * 4, 0)); \
     }
 #define CCVPE_W4_STORE_RAW(half)                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                      \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                    \
         const int px_ = r_px0 + (NT / 4) * (3 * (half) + i);                                             \
         if (px_ < 18 * 18) {                                                                             \
             const int py_ = (px_ * 3641) >> 16;              /* px / 18, exact for px < 324 */            \
@@ -199,9 +199,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // ---- transform: B^T d B of this lane's (channel, tile), 36 values -> V image ----
             // Two passes over the 6 x 6 patch, output rows 0-2 then 3-5 (18 live intermediates instead of 36); within a pass
             // the column transform is software pipelined: column c + 1 is being read while column c is transformed.
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                const int hf = NW == 4 ? pass : (wave >> 2);   // output rows 3 hf .. 3 hf + 2 (uniform per wave)
+            // one half-item: output rows 3 HF .. 3 HF + 2.  HF is a compile-time constant inside, so only the three needed rows
+            // of every column transform are computed (6 instead of 12 operations per column)
+            auto half_item = [&](auto hfc) {
+                constexpr int HF = decltype(hfc)::value;
                 float t[3][6];
                 float dc[2][6];
 #pragma unroll
@@ -214,18 +215,26 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     }
                     float u0, u1, u2, u3, u4, u5;
                     w4_bt(dc[c & 1][0], dc[c & 1][1], dc[c & 1][2], dc[c & 1][3], dc[c & 1][4], dc[c & 1][5], u0, u1, u2, u3, u4, u5);
-                    t[0][c] = hf ? u3 : u0; t[1][c] = hf ? u4 : u1; t[2][c] = hf ? u5 : u2;   // NW 8: hf is wave-uniform at run time
+                    t[0][c] = HF ? u3 : u0; t[1][c] = HF ? u4 : u1; t[2][c] = HF ? u5 : u2;
                 }
 #pragma unroll
                 for (int ii = 0; ii < 3; ++ii) {
                     float v0, v1, v2, v3, v4, v5;
                     w4_bt(t[ii][0], t[ii][1], t[ii][2], t[ii][3], t[ii][4], t[ii][5], v0, v1, v2, v3, v4, v5);
-                    // row i = 3 hf + ii; xi = 6 i + j; pairs (6i, 6i+1), (6i+2, 6i+3), (6i+4, 6i+5) = xp 3i .. 3i+2
-                    float* td = t_dst + hf * (9 * 128) + ii * (3 * 128);
+                    // row i = 3 HF + ii; xi = 6 i + j; pairs (6i, 6i+1), (6i+2, 6i+3), (6i+4, 6i+5) = xp 3i .. 3i+2
+                    float* td = t_dst + HF * (9 * 128) + ii * (3 * 128);
                     *reinterpret_cast<f32x2*>(td) = f32x2{v0, v1};
                     *reinterpret_cast<f32x2*>(td + 128) = f32x2{v2, v3};
                     *reinterpret_cast<f32x2*>(td + 256) = f32x2{v4, v5};
                 }
+            };
+            if (NW == 4) {              // both halves, one after the other (18 live intermediates instead of 36)
+                half_item(std::integral_constant<int, 0>{});
+                half_item(std::integral_constant<int, 1>{});
+            } else if (wave < 4) {      // NW 8: waves w and w + 4 share the item (wave-uniform branch)
+                half_item(std::integral_constant<int, 0>{});
+            } else {
+                half_item(std::integral_constant<int, 1>{});
             }
             __syncthreads();   // V image complete; every wave is done with the raw patch
             // ---- the patch after this one: next group of this tile, or the first group of the next tile ----
@@ -241,14 +250,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const unsigned wb = last_step ? w_base_n : w_base;
                 const int ksn = last_step ? g_begin * 4 : g * 4 + ks + 1;
                 const float* va = va0 + ks * (18 * 128);
-                f32x2 fa[2];
+                f32x2 fa[3];              // V pairs, read two pairs (4 MFMAs = 128 cycles) ahead of their use
                 fa[0] = *reinterpret_cast<const f32x2*>(va);
+                fa[1] = *reinterpret_cast<const f32x2*>(va + 128);
 #pragma unroll
                 for (int xp = 0; xp < 18; ++xp) {
-                    if (xp + 1 < 18) fa[(xp + 1) & 1] = *reinterpret_cast<const f32x2*>(va + (xp + 1) * 128);
+                    if (xp + 2 < 18) fa[(xp + 2) % 3] = *reinterpret_cast<const f32x2*>(va + (xp + 2) * 128);
                     __builtin_amdgcn_sched_barrier(0);   // keep the next pair's read above this pair's MFMAs
-                    acc[2 * xp] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[xp & 1].x, bq[2 * xp], acc[2 * xp], 0, 0, 0);
-                    acc[2 * xp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[xp & 1].y, bq[2 * xp + 1], acc[2 * xp + 1], 0, 0, 0);
+                    // weights as the A operand, V as the B operand: D[channel][tile], so a lane ends up with 4 consecutive
+                    // channels of ONE tile and the epilogue stores 16-byte pieces (the fragment layouts of A and B coincide)
+                    acc[2 * xp] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[2 * xp], fa[xp % 3].x, acc[2 * xp], 0, 0, 0);
+                    acc[2 * xp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[2 * xp + 1], fa[xp % 3].y, acc[2 * xp + 1], 0, 0, 0);
                     if (xp & 1) {   // a quad's MFMAs have issued: refill its weight registers for the next k-step
                         __builtin_amdgcn_sched_barrier(0);
                         CCVPE_W4_LOAD_B(wb, ksn, xp >> 1);
@@ -266,16 +278,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
 
         // ---- inverse transform A^T M A, bias, activation, store ----
+        // lane = (channel quad cq = lane >> 4, tile (ty, tx) = ((lane >> 2) & 3, lane & 3)): accumulator element i of xi is
+        // channel 4 cq + i of that tile, so the 4 x 4 output pixels of the tile leave as 16 float4 stores per lane
         {
-            const int n = (nb * NW + wave) * 16 + (lane & 15);
-            const float bias = (split || n >= p.N) ? 0.f : p.bias[n];
+            const int n = (nb * NW + wave) * 16 + 4 * (lane >> 4);
+            const bool nok = n < p.N;                                   // N % 4 == 0: the whole quad is in or out
+            const f32x4 bias = (split || !nok) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(p.bias + n);
+            const float lo = act == ACT_RELU ? 0.f : -__builtin_inff();   // ReLU as a select: no branch per store
             const size_t pix0 = ((size_t)b * p.H + (size_t)by * 16) * p.W + (size_t)bx * 16;
             float* obase = split ? p.partial + ((size_t)blockIdx.z * p.M + pix0) * p.N : p.dst[0].ptr + pix0 * ld + p.dst[0].coff;
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0x7fffffff, 0x00020000);
-            // lane part: tile row (lane >> 4) -> output rows 4*(lane>>4) .. +3, channel n; the (row, column) part is uniform
-            const unsigned o_lane = n < p.N ? (unsigned)((((lane >> 4) * 4 * p.W) * ld + n) * 4) : OOB;
+            const int oty = (lane >> 2) & 3, otx = lane & 3;
+            const unsigned o_lane = nok ? (unsigned)((((oty * 4) * p.W + otx * 4) * ld + n) * 4) : OOB;
+            // the 16 outputs of channel i go back into element i of acc[0..15] (dead by then): no second register set, and
+            // acc[4 a + c] ends up as the float4 of pixel (a, c)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {          // tile column: accumulator element i of every xi
+            for (int i = 0; i < 4; ++i) {
                 float tt[4][6];
 #pragma unroll
                 for (int q = 0; q < 6; ++q)
@@ -283,15 +301,32 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                           tt[0][q], tt[1][q], tt[2][q], tt[3][q]);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    float y[4];
-                    w4_at(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], tt[a][5], y[0], y[1], y[2], y[3]);
+                    float yy[4];
+                    w4_at(tt[a][0], tt[a][1], tt[a][2], tt[a][3], tt[a][4], tt[a][5], yy[0], yy[1], yy[2], yy[3]);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int soff = ((a * p.W + i * 4 + c) * ld) * 4;   // uniform
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(y[c] + bias, act)), o_rsrc, o_lane, soff, 0);
-                    }
+                    for (int c = 0; c < 4; ++c) acc[4 * a + c][i] = yy[c];
                 }
             }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float t = acc[4 * a + c][i] + bias[i];
+                        v[i] = t < lo ? lo : t;
+                    }
+                    const int soff = ((a * p.W + c) * ld) * 4;   // uniform
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), o_rsrc, o_lane, soff, 0);
+                    // gfx950: a vector instruction that overwrites the data registers of a 16-byte buffer store in the very next
+                    // issue slot can reach the registers before the store has read them (seen with v_pk_add_f32 behind a store
+                    // with an SGPR soffset, which hipcc's hazard recogniser exempts): lanes 12-15 of every row stored the NEXT
+                    // pixel's value.  Two wait states after each store; tests/test_isa_hazard.py checks the generated code.
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_nop 1");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
         if (!have_n) break;
 #pragma unroll
@@ -333,7 +368,7 @@ void launch_wino4_128(const ConvParams& p, hipStream_t s) { launch_wino4<8>(p, s
 bool conv_wino4_supported(const ConvParams& p) {
     return p.wino4_w != nullptr && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.mode == MODE_CONV &&
            p.gate == nullptr && p.resid == nullptr && p.ndst == 1 && !p.dst[0].split && !p.in_split && p.OH == p.H && p.OW == p.W &&
-           p.W % 16 == 0 && p.H % 16 == 0 && p.Cin % 8 == 0;
+           p.W % 16 == 0 && p.H % 16 == 0 && p.Cin % 8 == 0 && p.N % 4 == 0 && p.dst[0].ld % 4 == 0 && p.dst[0].coff % 4 == 0;
 }
 
 // Host-side weight transform: U = G g G^T (6 x 6) per (cout, cin) in double precision, stored as the B-fragment layout

@@ -24,13 +24,22 @@ def _asm(src):
     return src, subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
 
 
+_CACHE = {}
+
+
+def _all_asm():
+    if "r" not in _CACHE:
+        try:
+            subprocess.run([B._hipcc(), "--version"], capture_output=True, timeout=60, check=True)
+        except (OSError, subprocess.SubprocessError):
+            pytest.skip("hipcc not available")
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            _CACHE["r"] = list(ex.map(_asm, B.SOURCES))
+    return _CACHE["r"]
+
+
 def test_no_kernel_of_a_bf16x3_plan_has_the_op_sel_hazard_encoding():
-    try:
-        subprocess.run([B._hipcc(), "--version"], capture_output=True, timeout=60, check=True)
-    except (OSError, subprocess.SubprocessError):
-        pytest.skip("hipcc not available")
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        results = list(ex.map(_asm, B.SOURCES))
+    results = _all_asm()
     offenders = []
     seen_wino = False
     for src, r in results:
@@ -47,3 +56,41 @@ def test_no_kernel_of_a_bf16x3_plan_has_the_op_sel_hazard_encoding():
                     offenders.append(f"{src}: {kernel}: {line.strip()}")
     assert not offenders, "packed fp32 op_sel[1]=1 encodings in kernels a bf16x3 plan can launch:\n" + "\n".join(offenders[:20])
     assert seen_wino, "the lint pattern no longer matches the known instance in conv_wino_kernel - update the pattern"
+
+
+WIDE_STORE = re.compile(r"^\s*(buffer|global|flat|scratch)_store_dwordx[34]\s+v\[(\d+):(\d+)\]")
+VDST = re.compile(r"^\s*v_\w+\s+v(?:\[(\d+):(\d+)\]|(\d+))")
+
+
+def test_no_vector_write_lands_on_the_data_of_a_wide_store_in_the_next_slot():
+    """Second gfx950 hazard met in round 2 (conv_wino4_kernel<8> epilogue): `buffer_store_dwordx4 v[88:91], ..., s68 offen`
+    directly followed by `v_pk_add_f32 v[88:89], ...` stored the NEW v89 for lanes 12-15 of every 16 - the store had not read its
+    data yet.  hipcc's hazard recogniser only pads this write-after-read when the store has no SGPR soffset.  No kernel may
+    overwrite a register of a 12/16-byte store's data in the instruction slot right behind it (one independent instruction or
+    an s_nop in between is what the recogniser itself considers enough for the soffset-less form)."""
+    offenders = []
+    for src, r in _all_asm():
+        assert r.returncode == 0, f"{src}: {r.stderr[-2000:]}"
+        kernel = "?"
+        pending = None
+        for line in r.stdout.splitlines():
+            m = KERNEL.match(line)
+            if m:
+                kernel, pending = m.group(1), None
+                continue
+            t = line.strip()
+            if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+                continue            # comments, directives, labels: not an issue slot
+            if pending is not None:
+                lo, hi, text = pending
+                w = VDST.match(line)
+                if w and not t.startswith("v_cmp"):
+                    a = int(w.group(1) if w.group(1) is not None else w.group(3))
+                    b = int(w.group(2) if w.group(2) is not None else w.group(3))
+                    if a <= hi and b >= lo:
+                        offenders.append(f"{src}: {kernel}: {text}  ->  {t}")
+                pending = None
+            s = WIDE_STORE.match(line)
+            if s:
+                pending = (int(s.group(2)), int(s.group(3)), t)
+    assert not offenders, "vector write onto the data registers of the preceding wide store:\n" + "\n".join(offenders[:30])
