@@ -535,7 +535,7 @@ static int build_encoder(ccvpe_handle_s* h, EncoderW& e, const std::string& p) {
         std::string q = p + "._blocks." + std::to_string(i);
         const int mid = b.cin * b.e;
         if (b.e != 1 && (rc = pack_pointwise_bn(h, bw.expand, q + "._expand_conv.weight", q + "._bn0", mid, b.cin))) return rc;
-        if (b.e != 1 && mbconv_front_supported(b.k, b.s, b.cin, mid)) {
+        if (b.e != 1 && (mbconv_front_supported(b.k, b.s, b.cin, mid) || b.cin % 16 == 0)) {   // linear copy for the fused front kernels
             const auto& w = h->host[q + "._expand_conv.weight"];
             BnFold f = fold_bn(h, q + "._bn0");
             bw.exp_cinp = round_up(b.cin, 16);
@@ -706,19 +706,22 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         Tensor e = xin;
         static_pad(b.k, b.s, lo, hi);
         const int oh = conv_out(ch, b.k, b.s), ow = conv_out(cw, b.k, b.s);
-        const bool fused = b.e != 1 && bw.exp_lin != nullptr &&
-                           (h->fuse_mbconv == 2 || (h->fuse_mbconv == 1 && mbconv_front_profitable(b.k)));
+        MbFrontParams mp{};
+        mp.B = B; mp.H = ch; mp.W = cw; mp.Cin = b.cin; mp.cinp = bw.exp_cinp; mp.mid = mid;
+        mp.we = bw.exp_lin; mp.be = bw.expand.bias; mp.wd = bw.dw_w; mp.bd = bw.dw_b;
+        mp.k = b.k; mp.s = b.s; mp.pad_t = lo; mp.pad_l = lo; mp.circular = circular; mp.OH = oh; mp.OW = ow;
+        // small-spatial blocks: the whole expanded image of 16 channels lives in LDS (kernels_mbimg.hip); CCVPE_FUSE_MBCONV=0 / CCVPE_MBCONV_IMAGE=0 turn it off
+        static const bool image_off = getenv("CCVPE_MBCONV_IMAGE") && std::atoi(getenv("CCVPE_MBCONV_IMAGE")) == 0;
+        const bool image = b.e != 1 && bw.exp_lin != nullptr && h->fuse_mbconv != 0 && !image_off && h->cfg.reserved[0] == 0 && mbconv_image_supported(mp);
+        const bool fused = image || (b.e != 1 && bw.exp_lin != nullptr && mbconv_front_supported(b.k, b.s, b.cin, mid) &&
+                           (h->fuse_mbconv == 2 || (h->fuse_mbconv == 1 && mbconv_front_profitable(b.k))));
         Tensor d = pl.alloc(B, oh, ow, mid);
-        const int S = fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid, b.k, b.s);
+        const int S = image ? 1 : fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid, b.k, b.s);
         Tensor pool = pl.alloc(B, 1, S, mid);
         if (fused) {
-            MbFrontParams mp{};
-            mp.B = B; mp.H = ch; mp.W = cw; mp.Cin = b.cin; mp.cinp = bw.exp_cinp; mp.mid = mid;
-            mp.we = bw.exp_lin; mp.be = bw.expand.bias; mp.wd = bw.dw_w; mp.bd = bw.dw_b;
-            mp.k = b.k; mp.s = b.s; mp.pad_t = lo; mp.pad_l = lo; mp.circular = circular; mp.OH = oh; mp.OW = ow;
             pl.add(bn + ".expand_dw", {xin, d, pool}, [=](const Ctx& c) {
                 MbFrontParams q = mp; q.x = c.ptr(xin); q.out = c.ptr(d); q.pool = c.ptr(pool);
-                launch_mbconv_front(q, c.stream);
+                if (image) launch_mbconv_image(q, c.stream); else launch_mbconv_front(q, c.stream);
             }, 2.0 * B * ch * cw * b.cin * mid + 2.0 * B * oh * ow * mid * b.k * b.k, 4.0 * B * ((double)ch * cw * b.cin + (double)oh * ow * mid));
         } else {
         if (b.e != 1) {

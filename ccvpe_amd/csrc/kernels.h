@@ -169,6 +169,9 @@ void launch_mbconv_front(const MbFrontParams& p, hipStream_t s);
 int mbconv_front_tiles(int k, int s, int OH, int OW);
 bool mbconv_front_supported(int k, int s, int cin, int mid);
 bool mbconv_front_profitable(int k);
+// whole-image form for the small-spatial blocks (kernels_mbimg.hip): pool is [B][1][mid]
+bool mbconv_image_supported(const MbFrontParams& p);
+void launch_mbconv_image(const MbFrontParams& p, hipStream_t s);
 
 struct SeParams {
     const float* pool_partial; // [B][S][C]

@@ -1,0 +1,296 @@
+// Fused MBConv front half for the SMALL-spatial blocks (6..15 of EfficientNet-B0: 32x32 ... 5x8 pixels, 480-1152
+// expanded channels): 1x1 expand (+BN+swish) -> depthwise k x k (+BN+swish) -> SE pooling sums, with the expanded
+// activation of one whole image x 16 channels resident in LDS.
+//
+// Reference: MBConvBlock.forward, efficientnet_pytorch/model.py:103-110 (expand conv + bn0 + swish, static same /
+// horizontally circular padding utils.py:254-358, depthwise conv + bn1 + swish) and :114 (global average pool).
+//
+// Unfused, these blocks write the 6x-expanded tensor to HBM and read it straight back (block 9, batch 32: 88 MB each
+// way, two launches of 75 + 60 us).  The tile form of kernels_mbconv.hip does not pay here: an 8x8 tile of a 5x5 layer
+// recomputes 2.25x of the expand GEMM.  At these resolutions the WHOLE image of a 16-channel chunk fits in LDS
+// (36 x 36 pixels x 80 B = 104 KB), so nothing is recomputed and there is no halo logic on the input at all:
+//   * a 512-thread workgroup owns (sample, every CG-th chunk of 16 expanded channels);
+//   * expand: wave w takes m-tiles w, w + 8, ... of the [pixels x Cin] x [Cin x 16] GEMM, two at a time; the A operand
+//     (the block input, NHWC) goes from global memory / L2 straight into the MFMA registers, the B operand (16 rows of
+//     the expand weight) sits in registers for the chunk; bias + swish, then the accumulator rows are scattered into the
+//     zero-padded (or horizontally wrapped) E image through a pixel -> offset table;
+//   * depthwise: thread = (4 channels, TX x TY output patch); the K x K taps come from LDS once per chunk, every input
+//     row of the patch window is read once and used by all taps; bias + swish, 16-byte stores, channel sums for the
+//     squeeze-excite pool reduced in a fixed order (wave shuffles, then 8 partials through LDS) -> deterministic;
+//   * two barriers per chunk; the next chunk's expand weights are requested before the depthwise phase starts.
+// Samples are pinned to XCDs (sample b only on workgroups with id % 8 == b % 8) so the ~40-70 passes over a sample's
+// input hit that XCD's L2.
+#include "kernels.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace ccvpe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int EPS = 20;        // floats per pixel of the E image (16 + 4 pad: the MFMA-layout scatter is conflict-free)
+
+__device__ __forceinline__ float swish_i(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+
+struct MbImgParams {
+    MbFrontParams f;
+    int P, NMT;                // pixels of one input image, m-tiles of 16
+    int PT, PL;                // rows / columns of padding in front of the image inside the E image
+    int WPa, HPa;              // allocated E image size in pixels (>= the static padding; >= the patch windows of ragged sizes)
+    int NPX, NPY;              // output patches per row / column
+    int CG;                    // workgroups per sample
+    int nchunks;               // mid / 16
+};
+
+// NT = 512 threads (8 waves, one workgroup per CU) for the large images, 256 (two workgroups per CU, out of phase) when two
+// E images fit the LDS.  (Measured and dropped: keeping the input m-tiles of a <= 256-pixel image in registers across all
+// chunks - the expand and depthwise phases of a chunk simply add up, 55 + 40 us on block 12, and one workgroup per CU has
+// nothing to overlap them with.)
+template <int K, int S, int KCH, int TX, int TY, int NT>
+__global__ __launch_bounds__(NT) void mbconv_image_kernel(const MbImgParams q) {
+    constexpr int NWV = NT / 64;
+    constexpr int WW = (TX - 1) * S + K;
+    const MbFrontParams& p = q.f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int e_floats = (q.HPa * q.WPa + 1) * EPS;      // + one sink pixel
+    float* Es = smem;
+    int* ptab = reinterpret_cast<int*>(smem + e_floats);  // [NMT*16] pixel -> float offset in Es (sink past P)
+    int* dtab = ptab + q.NMT * 16;                         // [NMT*16] circular layers: offset of the wrapped copy (sink if none)
+    float* wks = reinterpret_cast<float*>(dtab + q.NMT * 16);   // [K*K][16] depthwise taps of the chunk
+    float* bds = wks + K * K * 16;                         // [16] depthwise bias
+    float* red = bds + 16;                                 // [NT/64][16] per-wave pooling sums
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // sample and chunk group of this workgroup; whole samples stay on one XCD when the batch allows it
+    int b, cg;
+    {
+        const int wg = blockIdx.x;
+        if (p.B % 8 == 0) { const int j = wg >> 3; b = (wg & 7) + 8 * (j / q.CG); cg = j % q.CG; }
+        else { b = wg / q.CG; cg = wg % q.CG; }
+    }
+    const int sink = q.HPa * q.WPa * EPS;
+
+    // ---- once per workgroup: zero the E image (padding ring, sink), build the scatter tables ----
+    for (int i = tid * 4; i < e_floats; i += NT * 4) *reinterpret_cast<f32x4*>(Es + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < q.NMT * 16; i += NT) {
+        int po = sink, dq = sink;
+        if (i < q.P) {
+            const int y = i / p.W, x = i - y * p.W;
+            po = ((y + q.PT) * q.WPa + x + q.PL) * EPS;
+            if (p.circular) {
+                const int pr = (p.OW - 1) * S + K - q.PL - p.W;       // columns of padding behind the image
+                if (x >= p.W - q.PL) dq = ((y + q.PT) * q.WPa + x - (p.W - q.PL)) * EPS;
+                else if (x < pr) dq = ((y + q.PT) * q.WPa + q.PL + p.W + x) * EPS;
+            }
+        }
+        ptab[i] = po; dtab[i] = dq;
+    }
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)b * q.P * p.Cin), 0, (unsigned)((size_t)q.P * p.Cin * 4), 0x00020000);
+    const unsigned a_lane = (unsigned)(((lane & 15) * p.Cin + 4 * (lane >> 4)) * 4);    // row (lane & 15) of an m-tile, channels 4 (lane >> 4)
+    const unsigned a_mt = (unsigned)(16 * p.Cin * 4);                                    // bytes per m-tile
+
+    const int dq4 = tid & 3, slot = tid >> 2;          // depthwise: channel quad, patch slot (128 slots)
+    const int npatch = q.NPX * q.NPY;
+
+    int ch = cg;                                        // chunk index; channels 16 ch .. 16 ch + 15
+    if (ch >= q.nchunks) return;
+    f32x4 wf[KCH];                                      // B fragments: We[16 ch + (lane & 15)][16 kc + 4 (lane >> 4) + e]
+#define CCVPE_MI_LOAD_W(c_)                                                                                      \
+    _Pragma("unroll") for (int kc = 0; kc < KCH; ++kc)                                                           \
+        wf[kc] = *reinterpret_cast<const f32x4*>(p.we + (size_t)((c_) * 16 + (lane & 15)) * p.cinp + kc * 16 + 4 * (lane >> 4));
+    CCVPE_MI_LOAD_W(ch);
+    // depthwise taps / bias of a chunk: fetched into registers a phase ahead, parked in LDS after the chunk barrier
+    const bool tap_thread = tid < K * K * 4, bias_thread = tid >= NT - 16;
+    f32x4 tapv = {0.f, 0.f, 0.f, 0.f};
+    float biasv = 0.f;
+#define CCVPE_MI_LOAD_TAPS(c_)                                                                                   \
+    {                                                                                                            \
+        if (tap_thread) tapv = *reinterpret_cast<const f32x4*>(p.wd + (size_t)(tid >> 2) * p.mid + (c_) * 16 + (tid & 3) * 4); \
+        if (bias_thread) biasv = p.bd[(c_) * 16 + tid - (NT - 16)];                                               \
+    }
+    CCVPE_MI_LOAD_TAPS(ch);
+    // A operand of one m-tile: KCH 16-byte pieces per lane; two register sets, the next m-tile always in flight
+    f32x4 abuf[2][KCH];
+#define CCVPE_MI_LOAD_A(set_, mt_)                                                                               \
+    _Pragma("unroll") for (int kc = 0; kc < KCH; ++kc)                                                           \
+        abuf[set_][kc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (mt_) < q.NMT ? a_lane + (unsigned)(mt_) * a_mt : 0x80000000u, kc * 64, 0));
+    // one m-tile: 4 KCH dependent MFMAs (the SIMD's other wave fills the dependent-issue gaps), bias + swish, scatter
+#define CCVPE_MI_SCATTER(acc_, mt_)                                                                              \
+    {                                                                                                            \
+        const int4 po = *reinterpret_cast<const int4*>(ptab + (mt_) * 16 + (lane >> 4) * 4);                     \
+        const int pos[4] = {po.x, po.y, po.z, po.w};                                                             \
+        float v[4];                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) { v[r] = swish_i(acc_[r] + be); Es[pos[r] + (lane & 15)] = v[r]; } \
+        if (p.circular) {                                                                                        \
+            const int4 dd = *reinterpret_cast<const int4*>(dtab + (mt_) * 16 + (lane >> 4) * 4);                 \
+            const int dds[4] = {dd.x, dd.y, dd.z, dd.w};                                                         \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) Es[dds[r] + (lane & 15)] = v[r];                       \
+        }                                                                                                        \
+    }
+#define CCVPE_MI_MTILE(set_, mt_)                                                                                \
+    {                                                                                                            \
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};                                                                        \
+        _Pragma("unroll") for (int kc = 0; kc < KCH; ++kc)                                   \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[set_][kc][e], wf[kc][e], acc, 0, 0, 0); \
+        CCVPE_MI_SCATTER(acc, mt_);                                                                              \
+    }
+    CCVPE_MI_LOAD_A(0, wave);
+    __syncthreads();
+
+    while (true) {
+        const int ch0 = ch * 16;
+        // depthwise taps and bias of this chunk -> LDS (read after the barrier below)
+        if (tap_thread) *reinterpret_cast<f32x4*>(wks + (tid >> 2) * 16 + (tid & 3) * 4) = tapv;
+        if (bias_thread) bds[tid - (NT - 16)] = biasv;
+        const float be = p.be[ch0 + (lane & 15)];
+
+        // ---- expand: m-tiles wave, wave + NWV, ...; set 0 holds the first one already ----
+            for (int mt = wave; mt < q.NMT;) {
+                CCVPE_MI_LOAD_A(1, mt + NWV);
+                CCVPE_MI_MTILE(0, mt);
+                mt += NWV;
+                if (mt >= q.NMT) break;
+                CCVPE_MI_LOAD_A(0, mt + NWV);
+                CCVPE_MI_MTILE(1, mt);
+                mt += NWV;
+            }
+        const int ch_n = ch + q.CG;
+        const bool have_n = ch_n < q.nchunks;
+        if (have_n) { CCVPE_MI_LOAD_W(ch_n); CCVPE_MI_LOAD_TAPS(ch_n); CCVPE_MI_LOAD_A(0, wave); }   // land under the depthwise phase
+        __syncthreads();                                   // E image, taps and bias of this chunk complete
+
+        // ---- depthwise K x K, stride S, from the E image ----
+        const f32x4 bd = *reinterpret_cast<const f32x4*>(bds + dq4 * 4);
+        f32x4 pool = {0.f, 0.f, 0.f, 0.f};
+        for (int pi = slot; pi < npatch; pi += NT / 4) {
+            const int py = pi / q.NPX, px = pi - py * q.NPX;
+            const int oy0 = py * TY, ox0 = px * TX;
+            const float* wp = Es + ((oy0 * S) * q.WPa + ox0 * S) * EPS + dq4 * 4;
+            f32x4 acc[TY][TX];
+#pragma unroll
+            for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < TX; ++tx) acc[ty][tx] = bd;
+            // one tap row at a time (a real loop: with all K*K taps and the whole window in registers the 5x5 forms spill, and
+            // hipcc hoists every LDS read of an unrolled form to the top whatever fences are placed)
+#pragma unroll 1
+            for (int ky = 0; ky < K; ++ky) {
+                f32x4 tap[K];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) tap[kx] = *reinterpret_cast<const f32x4*>(wks + (ky * K + kx) * 16 + dq4 * 4);
+#pragma unroll
+                for (int ty = 0; ty < TY; ++ty) {
+                    const float* rp = wp + ((ty * S + ky) * q.WPa) * EPS;
+                    f32x4 row[WW];
+#pragma unroll
+                    for (int wx = 0; wx < WW; ++wx) row[wx] = *reinterpret_cast<const f32x4*>(rp + wx * EPS);
+#pragma unroll
+                    for (int tx = 0; tx < TX; ++tx)
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx) acc[ty][tx] = __builtin_elementwise_fma(row[tx * S + kx], tap[kx], acc[ty][tx]);
+                }
+            }
+#pragma unroll
+            for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < TX; ++tx) {
+                    const int oy = oy0 + ty, ox = ox0 + tx;
+                    if (oy < p.OH && ox < p.OW) {
+                        f32x4 ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = swish_i(acc[ty][tx][e]);
+                        pool += ov;
+                        *reinterpret_cast<f32x4*>(p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * p.mid + ch0 + dq4 * 4) = ov;
+                    }
+                }
+        }
+        // channel sums: lanes with equal quad inside the wave (xor over lane bits 2..5), then the 8 waves through LDS
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pool[e] += __shfl_xor(pool[e], off);
+        if (lane < 4) *reinterpret_cast<f32x4*>(red + wave * 16 + lane * 4) = pool;
+        __syncthreads();                                   // E image free again; wave partials visible
+        if (tid < 16) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) s += red[w * 16 + tid];
+            p.pool[(size_t)b * p.mid + ch0 + tid] = s;     // [B][1][mid]: one partial row per sample
+        }
+        if (!have_n) break;
+        ch = ch_n;
+        // the sums above are read before any wave can pass the NEXT chunk's first barrier, where red is rewritten only after it
+    }
+#undef CCVPE_MI_LOAD_W
+#undef CCVPE_MI_LOAD_TAPS
+#undef CCVPE_MI_LOAD_A
+#undef CCVPE_MI_MTILE
+#undef CCVPE_MI_SCATTER
+}
+
+static bool img_geometry(const MbFrontParams& p, int tx, int ty, MbImgParams& q, size_t& lds) {
+    q.f = p;
+    q.P = p.H * p.W;
+    q.NMT = (q.P + 15) / 16;
+    q.PT = p.pad_t; q.PL = p.pad_l;
+    q.NPX = (p.OW + tx - 1) / tx; q.NPY = (p.OH + ty - 1) / ty;
+    q.WPa = std::max(p.W + q.PL, (q.NPX * tx - 1) * p.s + p.k);
+    q.HPa = std::max(p.H + q.PT, (q.NPY * ty - 1) * p.s + p.k);
+    q.nchunks = p.mid / 16;
+    lds = ((size_t)(q.HPa * q.WPa + 1) * EPS + 2 * (size_t)q.NMT * 16 + (size_t)p.k * p.k * 16 + 16 + 8 * 16) * sizeof(float);
+    return lds <= 150 * 1024;
+}
+
+// Patch per thread: 4 x 2 outputs (13 LDS reads per output for a 5x5 layer) - also on a 16 x 16 image, where it keeps only half
+// of a 256-thread workgroup busy but halves the LDS traffic of the 2 x 1 form (27 reads per output); 2 x 1 for the small
+// stride-2 images.
+static void patch_sel(int oh, int ow, int s, int& tx, int& ty) {
+    if (oh * ow >= 512 || s == 1) { tx = 4; ty = 2; } else { tx = 2; ty = 1; }
+}
+bool mbconv_image_supported(const MbFrontParams& p) {
+    const int kch = p.Cin / 16;
+    if (p.Cin % 16 != 0 || p.cinp != p.Cin || p.mid % 16 != 0 || p.W < 2 * p.k) return false;
+    const bool combo = (p.k == 3 && p.s == 1 && (kch == 5 || kch == 12)) || (p.k == 5 && p.s == 1 && (kch == 5 || kch == 7 || kch == 12)) ||
+                       (p.k == 5 && p.s == 2 && kch == 7);
+    if (!combo) return false;
+    int tx, ty;
+    patch_sel(p.OH, p.OW, p.s, tx, ty);
+    MbImgParams q;
+    size_t lds;
+    return img_geometry(p, tx, ty, q, lds);
+}
+
+template <int K, int S, int KCH, int TX, int TY, int NT>
+static void launch_img(const MbFrontParams& p, hipStream_t s) {
+    MbImgParams q;
+    size_t lds;
+    img_geometry(p, TX, TY, q, lds);
+    static LdsAttr attr;
+    auto kern = mbconv_image_kernel<K, S, KCH, TX, TY, NT>;
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
+    q.CG = std::max(1, std::min(q.nchunks, (NT == 512 ? 256 : 512) / std::max(1, p.B)));    // 8 waves per CU either way
+    hipLaunchKernelGGL(kern, dim3(p.B * q.CG), dim3(NT), lds, s, q);
+}
+
+template <int K, int S, int KCH>
+static void launch_img_p(const MbFrontParams& p, hipStream_t s) {
+    int tx, ty;
+    patch_sel(p.OH, p.OW, p.s, tx, ty);
+    MbImgParams q;
+    size_t lds;
+    img_geometry(p, tx, ty, q, lds);
+    const bool two = 2 * lds <= 150 * 1024;      // two workgroups of 256 threads per CU
+    if (tx == 4) { if (two) launch_img<K, S, KCH, 4, 2, 256>(p, s); else launch_img<K, S, KCH, 4, 2, 512>(p, s); }
+    else { if (two) launch_img<K, S, KCH, 2, 1, 256>(p, s); else launch_img<K, S, KCH, 2, 1, 512>(p, s); }
+}
+
+void launch_mbconv_image(const MbFrontParams& p, hipStream_t s) {
+    const int kch = p.Cin / 16;
+    if (p.k == 3 && p.s == 1) { if (kch == 5) launch_img_p<3, 1, 5>(p, s); else launch_img_p<3, 1, 12>(p, s); }
+    else if (p.k == 5 && p.s == 1) { if (kch == 5) launch_img_p<5, 1, 5>(p, s); else if (kch == 7) launch_img_p<5, 1, 7>(p, s); else launch_img_p<5, 1, 12>(p, s); }
+    else launch_img_p<5, 2, 7>(p, s);
+}
+
+}  // namespace ccvpe
