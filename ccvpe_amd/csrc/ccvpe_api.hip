@@ -1435,7 +1435,12 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
             }
             const long long blocks = conv_igemm_tile_blocks(q, t);
             static const bool no_split = getenv("CCVPE_TUNE_SPLITK") && std::atoi(getenv("CCVPE_TUNE_SPLITK")) == 0;
-            for (int split = 1; split <= (no_split ? 1 : 16); split *= 2) {
+            // the persistent Winograd grids also try odd split factors: 160 work items on 256 resident workgroups (conv6.0) are
+            // 3 rounds of quarter items with split 4 but 2 rounds of thirds with split 3
+            static const int SPLITS[] = {1, 2, 3, 4, 5, 6, 8, 12, 16};
+            for (int split : SPLITS) {
+                if (split > 1 && no_split) break;
+                if (split > 1 && (split & (split - 1)) && !conv_igemm_tile_is_wino(t)) continue;
                 if (split > 1 && conv_igemm_tile_is_pw(t)) break;   // the pointwise persistent tiles keep K whole
                 if (split > 1) {   // split-K only where the grid underfills the chip and K is deep enough
                     // (the persistent Winograd grid also splits when the tile count is an awkward multiple of the
