@@ -535,7 +535,7 @@ static int build_encoder(ccvpe_handle_s* h, EncoderW& e, const std::string& p) {
         std::string q = p + "._blocks." + std::to_string(i);
         const int mid = b.cin * b.e;
         if (b.e != 1 && (rc = pack_pointwise_bn(h, bw.expand, q + "._expand_conv.weight", q + "._bn0", mid, b.cin))) return rc;
-        if (b.e != 1 && (mbconv_front_supported(b.k, b.s, b.cin, mid) || b.cin % 16 == 0)) {   // linear copy for the fused front kernels
+        if (b.e != 1 && (mbconv_front_supported(b.k, b.s, b.cin, mid) || b.cin % 8 == 0)) {   // linear copy for the fused front kernels
             const auto& w = h->host[q + "._expand_conv.weight"];
             BnFold f = fold_bn(h, q + "._bn0");
             bw.exp_cinp = round_up(b.cin, 16);
@@ -716,7 +716,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         const bool fused = image || (b.e != 1 && bw.exp_lin != nullptr && mbconv_front_supported(b.k, b.s, b.cin, mid) &&
                            (h->fuse_mbconv == 2 || (h->fuse_mbconv == 1 && mbconv_front_profitable(b.k))));
         Tensor d = pl.alloc(B, oh, ow, mid);
-        const int S = image ? 1 : fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid, b.k, b.s);
+        const int S = image ? mbconv_image_strips(mp) : fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid, b.k, b.s);
         Tensor pool = pl.alloc(B, 1, S, mid);
         if (fused) {
             pl.add(bn + ".expand_dw", {xin, d, pool}, [=](const Ctx& c) {

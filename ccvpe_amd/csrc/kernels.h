@@ -169,8 +169,9 @@ void launch_mbconv_front(const MbFrontParams& p, hipStream_t s);
 int mbconv_front_tiles(int k, int s, int OH, int OW);
 bool mbconv_front_supported(int k, int s, int cin, int mid);
 bool mbconv_front_profitable(int k);
-// whole-image form for the small-spatial blocks (kernels_mbimg.hip): pool is [B][1][mid]
+// image-resident form (kernels_mbimg.hip): the whole image, or horizontal strips of it, per 16-channel chunk in LDS
 bool mbconv_image_supported(const MbFrontParams& p);
+int mbconv_image_strips(const MbFrontParams& p);   // pooling partial rows per sample ([B][strips][mid])
 void launch_mbconv_image(const MbFrontParams& p, hipStream_t s);
 
 struct SeParams {
