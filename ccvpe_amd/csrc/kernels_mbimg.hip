@@ -281,8 +281,8 @@ static void patch_sel(int oh, int ow, int s, int& tx, int& ty) {
 bool mbconv_image_supported(const MbFrontParams& p) {
     const int kch = p.cinp / 16;
     if (p.Cin % 8 != 0 || p.cinp % 16 != 0 || p.cinp < p.Cin || p.mid % 16 != 0 || p.W < 2 * p.k) return false;
-    const bool combo = (p.k == 3 && p.s == 1 && (kch == 5 || kch == 12)) || (p.k == 5 && p.s == 1 && (kch == 3 || kch == 5 || kch == 7 || kch == 12)) ||
-                       (p.k == 5 && p.s == 2 && (kch == 2 || kch == 7));
+    const bool combo = (p.k == 3 && p.s == 1 && (kch == 2 || kch == 5 || kch == 12)) || (p.k == 5 && p.s == 1 && (kch == 3 || kch == 5 || kch == 7 || kch == 12)) ||
+                       (p.k == 5 && p.s == 2 && (kch == 2 || kch == 7)) || (p.k == 3 && p.s == 2 && kch == 3);
     if (!combo) return false;
     int tx, ty;
     patch_sel(p.OH, p.OW, p.s, tx, ty);
@@ -330,9 +330,10 @@ static void launch_img_p(const MbFrontParams& p, hipStream_t s) {
 
 void launch_mbconv_image(const MbFrontParams& p, hipStream_t s) {
     const int kch = p.cinp / 16;
-    if (p.k == 3 && p.s == 1) { if (kch == 5) launch_img_p<3, 1, 5>(p, s); else launch_img_p<3, 1, 12>(p, s); }
+    if (p.k == 3 && p.s == 1) { if (kch == 2) launch_img_p<3, 1, 2>(p, s); else if (kch == 5) launch_img_p<3, 1, 5>(p, s); else launch_img_p<3, 1, 12>(p, s); }
     else if (p.k == 5 && p.s == 1) { if (kch == 3) launch_img_p<5, 1, 3>(p, s); else if (kch == 5) launch_img_p<5, 1, 5>(p, s); else if (kch == 7) launch_img_p<5, 1, 7>(p, s); else launch_img_p<5, 1, 12>(p, s); }
-    else { if (kch == 2) launch_img_p<5, 2, 2>(p, s); else launch_img_p<5, 2, 7>(p, s); }
+    else if (p.k == 5) { if (kch == 2) launch_img_p<5, 2, 2>(p, s); else launch_img_p<5, 2, 7>(p, s); }
+    else launch_img_p<3, 2, 3>(p, s);
 }
 
 }  // namespace ccvpe
