@@ -6,6 +6,9 @@
 // models.py:355-395 (ground descriptor heads: permute + Conv2d(H_f,1,1) + flatten).
 #include "kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace ccvpe {
 
 // x * sigmoid(x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division: the division expands to ~10
@@ -67,7 +70,108 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
     }
 }
 
+// Stem, tile form (default): a workgroup owns 32 x 8 output pixels x all 32 channels.  The (65 x 17 x 3)-float input patch is
+// staged in LDS once (coalesced rows; zero / wrapped outside the image), so the 27 taps of an output are LDS reads instead
+// of 27 global loads each touching 8 addresses (the pixel form above sat at ~2 TB/s on load issue).  Thread = (channel quad,
+// column of the tile): its 8 output rows share input rows (17 x 9 = 153 reads for 8 outputs), the 27 x 4 weights stay in
+// registers, stores are 16 B per lane with the 8 quads of a pixel contiguous.  Persistent grid.
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+static constexpr int ST_TW = 32, ST_TH = 8;
+static constexpr int ST_PW = 2 * ST_TW + 1, ST_PH = 2 * ST_TH + 1;   // input patch
+static constexpr int ST_PITCH = ST_PW + 2;                            // floats per patch row
+
+__global__ __launch_bounds__(256) void stem_tile_kernel(const StemParams p) {
+    __shared__ float patch[3 * ST_PH * ST_PITCH];
+    const int tid = threadIdx.x;
+    const int cg = tid & 7, col = tid >> 3;                           // channel quad, tile column
+    f32x4s w[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) w[i] = *reinterpret_cast<const f32x4s*>(p.w + i * 32 + cg * 4);
+    const f32x4s bias = *reinterpret_cast<const f32x4s*>(p.bias + cg * 4);
+    const int tiles_x = (p.OW + ST_TW - 1) / ST_TW, tiles_y = (p.OH + ST_TH - 1) / ST_TH;
+    const int tiles = p.B * tiles_x * tiles_y;
+    const int plane = p.H * p.W;
+    // the next tile's patch is fetched into registers while this one is computed (NPRE values per thread)
+    constexpr int NPRE = (3 * ST_PH * ST_PW + 255) / 256;
+    float pre[NPRE];
+    auto fetch = [&](int tl) {
+        const int b = tl / (tiles_x * tiles_y);
+        const int r = tl - b * (tiles_x * tiles_y);
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int iy0 = ty * ST_TH * 2 - p.pad_t, ix0 = tx * ST_TW * 2 - p.pad_l;
+        const float* inb = p.in + (size_t)b * 3 * plane;
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + j * 256;
+            const int c = i / (ST_PH * ST_PW), rem = i - c * (ST_PH * ST_PW);
+            const int y = rem / ST_PW, x = rem - y * ST_PW;
+            const int iy = iy0 + y;
+            int ix = ix0 + x;
+            bool ok = i < 3 * ST_PH * ST_PW && (unsigned)iy < (unsigned)p.H;
+            if (p.circular) { if (ix < 0) ix += p.W; else if (ix >= p.W) ix -= p.W; }
+            ok = ok && (unsigned)ix < (unsigned)p.W;
+            pre[j] = ok ? inb[c * plane + iy * p.W + ix] : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int b = tile / (tiles_x * tiles_y);
+        const int r = tile - b * (tiles_x * tiles_y);
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+        __syncthreads();                                              // previous tile's readers are done with the patch
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + j * 256;
+            if (i < 3 * ST_PH * ST_PW) {
+                const int c = i / (ST_PH * ST_PW), rem = i - c * (ST_PH * ST_PW);
+                const int y = rem / ST_PW, x = rem - y * ST_PW;
+                patch[(c * ST_PH + y) * ST_PITCH + x] = pre[j];
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);
+        f32x4s acc[ST_TH];
+#pragma unroll
+        for (int i = 0; i < ST_TH; ++i) acc[i] = bias;
+        const float* pp = patch + 2 * col;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int y = 0; y < ST_PH; ++y) {
+                const float v0 = pp[(c * ST_PH + y) * ST_PITCH], v1 = pp[(c * ST_PH + y) * ST_PITCH + 1], v2 = pp[(c * ST_PH + y) * ST_PITCH + 2];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    if ((y - ky) < 0 || ((y - ky) & 1) || (y - ky) / 2 >= ST_TH) continue;
+                    const int i = (y - ky) / 2;                       // output row fed by patch row y through tap row ky
+                    // 4 channels per tap on two v_pk_fma_f32 (the input value is broadcast through op_sel_hi, no move)
+                    acc[i] = __builtin_elementwise_fma(f32x4s{v0, v0, v0, v0}, w[(c * 3 + ky) * 3], acc[i]);
+                    acc[i] = __builtin_elementwise_fma(f32x4s{v1, v1, v1, v1}, w[(c * 3 + ky) * 3 + 1], acc[i]);
+                    acc[i] = __builtin_elementwise_fma(f32x4s{v2, v2, v2, v2}, w[(c * 3 + ky) * 3 + 2], acc[i]);
+                }
+            }
+        const int ox = ox0 + col;
+        if (ox < p.OW) {
+#pragma unroll
+            for (int i = 0; i < ST_TH; ++i) {
+                const int oy = oy0 + i;
+                if (oy >= p.OH) break;
+                f32x4s o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = swishf(acc[i][e]);
+                *reinterpret_cast<f32x4s*>(p.out + (((size_t)b * p.OH + oy) * p.OW + ox) * 32 + cg * 4) = o;
+            }
+        }
+    }
+}
+
 void launch_stem(const StemParams& p, hipStream_t s) {
+    static const bool pixel_form = getenv("CCVPE_STEM_TILE") && std::atoi(getenv("CCVPE_STEM_TILE")) == 0;   // A/B switch
+    if (!pixel_form) {
+        const int tiles = p.B * ((p.OW + ST_TW - 1) / ST_TW) * ((p.OH + ST_TH - 1) / ST_TH);
+        hipLaunchKernelGGL(stem_tile_kernel, dim3(std::min(tiles, 256 * 6)), dim3(256), 0, s, p);
+        return;
+    }
     long long total = (long long)p.B * p.OH * p.OW * 8;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -252,6 +356,13 @@ __global__ __launch_bounds__(256) void se_excite_kernel(const SeParams p, const 
 }
 
 void launch_se(const SeParams& p, hipStream_t s) {
+    if (p.S <= 16) {   // the image-resident front kernels leave 1-16 partial rows per sample: the squeeze kernel sums them itself
+        SeParams q = p;
+        q.SC = p.S;
+        hipLaunchKernelGGL(se_squeeze_kernel, dim3(p.SQ, p.B), dim3(256), 0, s, q, (const float*)p.pool_partial, p.sq);
+        hipLaunchKernelGGL(se_excite_kernel, dim3((p.C + 255) / 256, p.B), dim3(256), 0, s, p, (const float*)p.sq);
+        return;
+    }
     hipLaunchKernelGGL(se_pool_kernel, dim3((p.C + 63) / 64, p.B, p.SC), dim3(256), 0, s, p, p.pooled);
     hipLaunchKernelGGL(se_squeeze_kernel, dim3(p.SQ, p.B), dim3(256), 0, s, p, (const float*)p.pooled, p.sq);
     hipLaunchKernelGGL(se_excite_kernel, dim3((p.C + 255) / 256, p.B), dim3(256), 0, s, p, (const float*)p.sq);
