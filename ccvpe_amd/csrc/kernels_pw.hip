@@ -166,6 +166,8 @@ static const PwTile PW_TILES[] = {
     {16, 48, "conv_pw_48", launch_pw<3>},
     {16, 80, "conv_pw_80", launch_pw<5>},
     {16, 128, "conv_pw_128", launch_pw<8>},
+    {16, 64, "conv_pw_64", launch_pw<4>},
+    {16, 160, "conv_pw_160", launch_pw<10>},
 };
 int pw_num_tiles() { return (int)(sizeof(PW_TILES) / sizeof(PW_TILES[0])); }
 const PwTile* pw_tile(int i) { return &PW_TILES[i]; }
