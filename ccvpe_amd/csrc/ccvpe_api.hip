@@ -1671,7 +1671,7 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
                     q.M = op.gemm_m; q.N = op.gemm_n;
                     const double util = conv_igemm_tile_util(q, tile & 0xff);
                     const double mn_pad = util > 0 ? (double)op.gemm_m * op.gemm_n / util : 0.0;
-                    if (conv_igemm_tile_is_wino4(tile)) issued = 2.0 * mn_pad * 2.25 * ((op.conv_cin + 15) / 16 * 16);   // 36 products per 4x4 tile
+                    if (conv_igemm_tile_is_wino4(tile)) issued = 2.0 * mn_pad * 2.25 * ((op.conv_cin + 3) / 4 * 4);   // 36 products per 4x4 tile; k-steps of 4 channels, all-zero ones skipped
                     else if (conv_igemm_tile_is_wino(tile)) issued = 2.0 * mn_pad * 4.0 * op.conv_cin;
                     else issued = 2.0 * mn_pad * op.gemm_kpad * (conv_igemm_tile_is_bf16x3(tile) ? 3.0 : 1.0);
                 }

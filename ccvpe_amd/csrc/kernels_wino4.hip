@@ -144,6 +144,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         g_end = min(g_begin + per, ngr_all);
     }
     if (g_begin >= g_end) return;   // empty split-K slice (the host never launches one)
+    // the layer's last group may hold only 8 real channels (Cin % 16 == 8: 40, 56, 104, 200 ...): its k-steps 2 and 3 would
+    // multiply zeros, so they are neither transformed nor run (conv2.2: 10 k-steps instead of 12)
+    const int tail_ks = (p.Cin - (ngr_all - 1) * W4_GCH + 3) >> 2;
 
     f32x4 raw[3];
     float bq[36];             // B fragments of the current k-step, refilled in place for the next one
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
         for (int g = g_begin; g < g_end; ++g) {
             const bool last_group = g == g_end - 1;
+            const int nks = g == ngr_all - 1 ? tail_ks : 4;
             // ---- transform: B^T d B of this lane's (channel, tile), 36 values -> V image ----
             // Two passes over the 6 x 6 patch, output rows 0-2 then 3-5 (18 live intermediates instead of 36); within a pass
             // the column transform is software pipelined: column c + 1 is being read while column c is transformed.
@@ -228,7 +232,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     *reinterpret_cast<f32x2*>(td + 256) = f32x2{v4, v5};
                 }
             };
-            if (NW == 4) {              // both halves, one after the other (18 live intermediates instead of 36)
+            if (tks >= nks) {           // k-step beyond the layer's channels: nothing to transform (wave-uniform)
+            } else if (NW == 4) {       // both halves, one after the other (18 live intermediates instead of 36)
                 half_item(std::integral_constant<int, 0>{});
                 half_item(std::integral_constant<int, 1>{});
             } else if (wave < 4) {      // NW 8: waves w and w + 4 share the item (wave-uniform branch)
@@ -245,8 +250,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // ---- MFMA phase: 4 k-steps x 36 xi (a real loop: unrolled, hipcc renames the 144 accumulator and 36 weight
             //      registers per k-step and spills a hundred of them) ----
 #pragma unroll 1
-            for (int ks = 0; ks < 4; ++ks) {
-                const bool last_step = last_group && ks == 3;
+            for (int ks = 0; ks < nks; ++ks) {
+                const bool last_step = last_group && ks == nks - 1;
                 const unsigned wb = last_step ? w_base_n : w_base;
                 const int ksn = last_step ? g_begin * 4 : g * 4 + ks + 1;
                 const float* va = va0 + ks * (18 * 128);
