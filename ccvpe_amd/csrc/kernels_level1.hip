@@ -186,19 +186,31 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
             const float* dp0 = Ds + ((pa0 / AT) * DT + pa0 % AT) * PS + 4 * (lane >> 4);
             const float* dp1 = Ds + ((pa1 / AT) * DT + pa1 % AT) * PS + 4 * (lane >> 4);
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (mt1 < NMT) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int toff = ((t / 3) * DT + (t % 3)) * PS;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(dp0 + toff);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(dp1 + toff);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wa[t].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wa[t].x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wa[t].y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wa[t].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wa[t].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wa[t].z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wa[t].w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wa[t].w, acc1, 0, 0, 0);
+                for (int t = 0; t < 9; ++t) {
+                    const int toff = ((t / 3) * DT + (t % 3)) * PS;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(dp0 + toff);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(dp1 + toff);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wa[t].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wa[t].x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wa[t].y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wa[t].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wa[t].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wa[t].z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wa[t].w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wa[t].w, acc1, 0, 0, 0);
+                }
+            } else {   // the last m-tile of a wave has no partner (21 m-tiles over 4 waves x 2 chains): one chain, no padding MFMAs
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int toff = ((t / 3) * DT + (t % 3)) * PS;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(dp0 + toff);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wa[t].x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wa[t].y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wa[t].z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wa[t].w, acc0, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
