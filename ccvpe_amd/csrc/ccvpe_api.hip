@@ -1937,7 +1937,7 @@ int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Ci
         tmp.dev_alloc_bytes.push_back(fl * sizeof(float));
         p.partial = (float*)d; p.partial_floats = fl;
     }
-    if (conv_igemm_tile_is_wino(tile) && !conv_wino_tile_supported(p, tile)) { cleanup(); return fail(CCVPE_EINVAL, "layer is not Winograd-shaped (3x3, stride 1, pad 1, W %% 16 == 0, H %% 16 == 0; F(4x4): >= 40 output channels)"); }
+    if (conv_igemm_tile_is_wino(tile) && !conv_wino_tile_supported(p, tile)) { cleanup(); return fail(CCVPE_EINVAL, "layer is not Winograd-shaped (3x3, stride 1, pad 1, W %% 16 == 0, H %% 16 == 0, output channels a multiple of 4; F(4x4): >= 40 of them)"); }
     if (launch_conv_igemm(p, tile, st) != 0) { cleanup(); return fail(CCVPE_EINVAL, "unsupported conv geometry (KH*KW <= 16, Cin %% 8 == 0)"); }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && iters > 0 && ms) {

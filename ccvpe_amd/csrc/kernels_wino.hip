@@ -266,10 +266,10 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int x = g * 2 + e;
-                    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][e][0].x, bq[x].x, acc[x][0], 0, 0, 0);
-                    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][e][1].x, bq[x].x, acc[x][1], 0, 0, 0);
-                    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][e][0].y, bq[x].y, acc[x][0], 0, 0, 0);
-                    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][e][1].y, bq[x].y, acc[x][1], 0, 0, 0);
+                    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[x].x, fa[cur][e][0].x, acc[x][0], 0, 0, 0);
+                    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[x].x, fa[cur][e][1].x, acc[x][1], 0, 0, 0);
+                    acc[x][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[x].y, fa[cur][e][0].y, acc[x][0], 0, 0, 0);
+                    acc[x][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[x].y, fa[cur][e][1].y, acc[x][1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 CCVPE_WINO_LOAD_B(wb, chn, g);
@@ -279,18 +279,25 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
         }
 
         // ---- inverse transform A^T M A, bias, activation, store ----
-        // Vector ALU work here also costs matrix-pipe slots, so: the transform runs on the accumulator quads (four
-        // horizontally adjacent tiles per lane -> packed fp32 adds), and the stores are buffer stores whose per-lane
-        // offset is computed once per tile - the (tile, pixel) part of every address is uniform and rides in soffset.
+        // The weights are the A operand of the MFMAs, so the accumulators are channel-major: lane = (channel quad lane >> 4, tile
+        // lane & 15 of the half: row (lane & 15) >> 3, column (lane & 15) & 7) and element i of an accumulator is channel
+        // 4 (lane >> 4) + i.  The transform runs on the channel quads (packed fp32 adds) and every output pixel of the tile
+        // leaves as ONE 16-byte buffer store (8 per lane instead of 32 dword stores with a branch on the activation each); the
+        // (half, pixel) part of every address is uniform and rides in soffset.
         {
-            const int n = (nb * NW + wave) * 16 + (lane & 15);
-            const float bias = (split || n >= p.N) ? 0.f : p.bias[n];
+            const int n = (nb * NW + wave) * 16 + 4 * (lane >> 4);
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+            if (!split) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bias[i] = n + i < p.N ? p.bias[n + i] : 0.f;
+            }
+            const float lo = act == ACT_RELU ? 0.f : -__builtin_inff();   // ReLU as a select: no branch per store
             // first output pixel of this wave's tile set
             const size_t pix0 = ((size_t)b * p.H + (size_t)(by * NM + wset) * 8) * p.W + (size_t)bx * 16;
             float* obase = split ? p.partial + ((size_t)blockIdx.z * p.M + pix0) * p.N : p.dst[0].ptr + pix0 * ld + p.dst[0].coff;
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0x7fffffff, 0x00020000);
-            // lane part: tile row 2*h + (lane >> 5) of the set, tile column 4 * ((lane >> 4) & 1) + i, channel n
-            const unsigned o_lane = n < p.N ? (unsigned)((((lane >> 5) * 2 * p.W + ((lane >> 4) & 1) * 8) * ld + n) * 4) : OOB;
+            const int tl = lane & 15;
+            const unsigned o_lane = n < p.N ? (unsigned)((((tl >> 3) * 2 * p.W + (tl & 7) * 2) * ld + n) * 4) : OOB;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 f32x4 tt[2][4];
@@ -305,12 +312,17 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
                     y[0] = tt[a][0] + tt[a][1] + tt[a][2] + bias;
                     y[1] = tt[a][1] - tt[a][2] - tt[a][3] + bias;
 #pragma unroll
-                    for (int dx = 0; dx < 2; ++dx)
+                    for (int dx = 0; dx < 2; ++dx) {
+                        f32x4 v;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int soff = (((h * 4 + a) * p.W + i * 2 + dx) * ld) * 4;   // uniform
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, apply_act(y[dx][i], act)), o_rsrc, o_lane, soff, 0);
-                        }
+                        for (int i = 0; i < 4; ++i) v[i] = y[dx][i] < lo ? lo : y[dx][i];
+                        const int soff = (((h * 4 + a) * p.W + dx) * ld) * 4;   // uniform
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), o_rsrc, o_lane, soff, 0);
+                        // two wait states before anything may overwrite the store's data registers (gfx950: tests/test_isa_hazard.py)
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_nop 1");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }
@@ -369,7 +381,7 @@ const WinoTile* wino_tile(int i) { return &WINO_TILES[i]; }
 bool conv_wino_supported(const ConvParams& p) {
     return p.wino_w != nullptr && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && p.mode == MODE_CONV &&
            p.gate == nullptr && p.resid == nullptr && p.ndst == 1 && !p.dst[0].split && !p.in_split && p.OH == p.H && p.OW == p.W &&
-           p.W % 16 == 0 && p.H % 16 == 0 && p.Cin % 8 == 0;
+           p.W % 16 == 0 && p.H % 16 == 0 && p.Cin % 8 == 0 && p.N % 4 == 0 && p.dst[0].ld % 4 == 0 && p.dst[0].coff % 4 == 0;
 }
 
 // Host-side weight transform: U = G g G^T per (cout, cin) in double precision, stored in the LDS image order

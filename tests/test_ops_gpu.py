@@ -74,7 +74,8 @@ WINO_SHAPES = [
     (1, 16, 16, 8, 16),
     (3, 16, 16, 64, 88),
     (2, 48, 32, 24, 40),
-    (1, 32, 48, 104, 17),
+    (1, 32, 48, 104, 17),      # not a multiple of 4 channels: every Winograd tile refuses it
+    (1, 32, 48, 104, 20),      # a partly filled last 16-channel slice
     (2, 16, 16, 200, 160),
     (1, 64, 64, 16, 100),
 ]
@@ -97,7 +98,7 @@ def test_winograd_tiles_match_torch(shape):
         for t in tiles:
             name = lib.ccvpe_op_tile_name(t).decode()
             f4 = "wino4" in name
-            if f4 and Cout < 40:      # F(4x4,3x3) weights are only packed for layers of >= 40 output channels
+            if (f4 and Cout < 40) or Cout % 4:   # F(4x4,3x3) weights are only packed for layers of >= 40 output channels; both forms store 4 channels per lane
                 with pytest.raises(_lib.CcvpeError):
                     _lib.op_conv2d(x, w, b, 1, 1, act, t)
                 continue
