@@ -75,8 +75,9 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
     f32x4 wa[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wa[t] = *reinterpret_cast<const f32x4*>(p.wa + (size_t)(lane & 15) * 144 + t * 16 + 4 * (lane >> 4));
-    const float bd = p.bd[lane & 15];
-    const float ba = p.ba[lane & 15];
+    // channel-major accumulators (weights are the A operand of the MFMAs): a lane holds channels 4 (lane >> 4) .. + 3 of ONE pixel
+    const f32x4 bd = *reinterpret_cast<const f32x4*>(p.bd + 4 * (lane >> 4));
+    const f32x4 ba = *reinterpret_cast<const f32x4*>(p.ba + 4 * (lane >> 4));
     const float* __restrict__ wt = p.wt;   // [9][COUT][16], uniform -> scalar loads; a channel pair is one aligned SGPR pair
 
     // X tile staging: float4 item i = tid + it*256 -> pixel i / c4n, channels 4*(i % c4n)
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
         // two independent accumulator chains per wave (m-tiles mt and mt+1) hide the dependent-MFMA latency
         {
             const int dy = wave >> 1, dx = wave & 1;
-            float* dsub = Ds + (dy * DT + dx) * PS + (lane & 15);
+            float* dsub = Ds + (dy * DT + dx) * PS + 4 * (lane >> 4);
             for (int mt0 = 0; mt0 < 7; mt0 += 2) {
                 const int mt1 = mt0 + 1;               // may be 7 (invalid): computed on clamped rows, never stored
                 const float* ap0 = Xs + min(mt0 * 16 + (lane & 15), XT * XT - 1) * XS + 4 * (lane >> 4);
@@ -142,36 +143,29 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
                     const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap0 + kc * 16);
                     const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap1 + kc * 16);
                     const f32x4 w = wd[kc];
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w.x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w.x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w.y, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w.y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w.z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w.z, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w.w, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w.w, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a0.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a1.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a0.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a1.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a0.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a1.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a0.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a1.w, acc1, 0, 0, 0);
                 }
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const int mt = h2 ? mt1 : mt0;
                     if (mt >= 7) continue;
                     const f32x4 acc = h2 ? acc1 : acc0;
-                    const int4 dt = *reinterpret_cast<const int4*>(dtab + mt * 16 + (lane >> 4) * 4);
-                    const int dts[4] = {dt.x, dt.y, dt.z, dt.w};
+                    const int px = mt * 16 + (lane & 15);           // X pixel of this lane's accumulator (>= 100: sink row)
+                    const int dto = dtab[px];
                     if (interior) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dsub[dts[r]] = acc[r] + bd;     // rows >= 100 land in the sink rows
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int px = mt * 16 + (lane >> 4) * 4 + r;       // X pixel of this accumulator row
-                            if (px < XT * XT) {
-                                const int dr = 2 * (px / XT) + dy, dc = 2 * (px % XT) + dx;          // position in the D tile
-                                const int gy = Y0 - 2 + dr, gx = X0 - 2 + dc;                        // position in the image
-                                const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                                dsub[dts[r]] = in ? acc[r] + bd : 0.f;
-                            }
-                        }
+                        *reinterpret_cast<f32x4*>(dsub + dto) = acc + bd;
+                    } else if (px < XT * XT) {
+                        const int dr = 2 * (px / XT) + dy, dc = 2 * (px % XT) + dx;          // position in the D tile
+                        const int gy = Y0 - 2 + dr, gx = X0 - 2 + dc;                        // position in the image
+                        const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                        *reinterpret_cast<f32x4*>(dsub + dto) = in ? acc + bd : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
             }
@@ -192,24 +186,24 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
                     const int toff = ((t / 3) * DT + (t % 3)) * PS;
                     const f32x4 a0 = *reinterpret_cast<const f32x4*>(dp0 + toff);
                     const f32x4 a1 = *reinterpret_cast<const f32x4*>(dp1 + toff);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wa[t].x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wa[t].x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wa[t].y, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wa[t].y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wa[t].z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wa[t].z, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wa[t].w, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wa[t].w, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].x, a0.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].x, a1.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].y, a0.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].y, a1.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].z, a0.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].z, a1.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].w, a0.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].w, a1.w, acc1, 0, 0, 0);
                 }
             } else {   // the last m-tile of a wave has no partner (21 m-tiles over 4 waves x 2 chains): one chain, no padding MFMAs
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int toff = ((t / 3) * DT + (t % 3)) * PS;
                     const f32x4 a0 = *reinterpret_cast<const f32x4*>(dp0 + toff);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wa[t].x, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wa[t].y, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wa[t].z, acc0, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wa[t].w, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].x, a0.x, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].y, a0.y, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].z, a0.z, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t].w, a0.w, acc0, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -217,21 +211,16 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
                 const int mt = h2 ? mt1 : mt0;
                 if (mt >= NMT) continue;
                 const f32x4 acc = h2 ? acc1 : acc0;
-                float* asub = As + (mt * 16 + (lane >> 4) * 4) * PS + (lane & 15);
-                if (interior) {
+                const int q = mt * 16 + (lane & 15);                // A pixel of this lane's accumulator (>= 324: sink row)
+                f32x4 v = acc + ba;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) asub[r * PS] = fmaxf(acc[r] + ba, 0.f);     // rows >= 324 are sink rows
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int q = mt * 16 + (lane >> 4) * 4 + r;
-                        if (q < AT * AT) {
-                            const int gy = Y0 - 1 + q / AT, gx = X0 - 1 + q % AT;
-                            const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                            asub[r * PS] = in ? fmaxf(acc[r] + ba, 0.f) : 0.f;
-                        }
-                    }
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                if (!interior) {
+                    const int gy = Y0 - 1 + q / AT, gx = X0 - 1 + q % AT;
+                    const bool in = q < AT * AT && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                    if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+                *reinterpret_cast<f32x4*>(As + q * PS + 4 * (lane >> 4)) = v;
             }
         }
         __syncthreads();
