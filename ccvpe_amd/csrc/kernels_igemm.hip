@@ -27,13 +27,19 @@ template <> struct Mfma<32> {
     using acc_t = f32x16;
     static constexpr int NACC = 16;
     static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+    // D[n][m] of the swapped product: lane holds column m = lane & 31 and, per quad q = 0..3, rows n = 8 q + 4 (lane >> 5) + 0..3
+    static constexpr int NQ = 4;
+    static __device__ __forceinline__ int mrow(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int ncol(int q, int lane) { return 8 * q + 4 * (lane >> 5); }
 };
 template <> struct Mfma<16> {
     using acc_t = f32x4;
     static constexpr int NACC = 4;
     static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row(int r, int lane) { return (lane >> 4) * 4 + r; }
+    // lane holds column m = lane & 15 and rows n = 4 (lane >> 4) + 0..3
+    static constexpr int NQ = 1;
+    static __device__ __forceinline__ int mrow(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int ncol(int, int lane) { return 4 * (lane >> 4); }
 };
 
 // NS = LDS stages: 2 (next tile stored while the current one is multiplied, one barrier per K tile) or 1 (half the
@@ -187,10 +193,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = M::run(a[cur][i].x, b[cur][j].x, acc[i][j]);
-                    acc[i][j] = M::run(a[cur][i].y, b[cur][j].y, acc[i][j]);
-                    acc[i][j] = M::run(a[cur][i].z, b[cur][j].z, acc[i][j]);
-                    acc[i][j] = M::run(a[cur][i].w, b[cur][j].w, acc[i][j]);
+                    // weights as the A operand: accumulators are channel-major (element r of a quad = 4 consecutive n of ONE
+                    // row m), so the epilogue writes 16-byte pieces of C rows
+                    acc[i][j] = M::run(b[cur][j].x, a[cur][i].x, acc[i][j]);
+                    acc[i][j] = M::run(b[cur][j].y, a[cur][i].y, acc[i][j]);
+                    acc[i][j] = M::run(b[cur][j].z, a[cur][i].z, acc[i][j]);
+                    acc[i][j] = M::run(b[cur][j].w, a[cur][i].w, acc[i][j]);
                 }
         }
         // ... and the LDS stores (which wait for those loads) BELOW it
@@ -209,19 +217,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int LDC = BN + 4;
     float* Cs = smem;
     const bool split = p.splitk > 1;
-    const int col = lane % MT;
+    const int act = split ? ACT_NONE : p.act;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int nl = wn * WN + j * MT + col;
-        const int n = n0 + nl;
-        const float bias = (!split && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int q = 0; q < M::NQ; ++q) {
+            const int nl = wn * WN + j * MT + M::ncol(q, lane);
+            const int n = n0 + nl;
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+            if (!split) {
 #pragma unroll
-            for (int r = 0; r < M::NACC; ++r) {
-                const int ml = wm * WM + i * MT + M::row(r, lane);
-                const float v = acc[i][j][r] + bias;
-                Cs[ml * LDC + nl] = split ? v : apply_act(v, p.act);
+                for (int e = 0; e < 4; ++e) bias[e] = n + e < p.N ? p.bias[n + e] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ml = wm * WM + i * MT + M::mrow(lane);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + bias[e];
+                if (act == ACT_SWISH) {          // uniform: one branch per quad instead of one per element
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], ACT_SWISH);
+                } else if (act == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *reinterpret_cast<f32x4*>(Cs + ml * LDC + nl) = v;
             }
         }
     }
