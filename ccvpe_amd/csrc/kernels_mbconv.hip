@@ -218,19 +218,19 @@ __global__ __launch_bounds__(64, KCH == 1 ? 3 : 2) void mbconv_front_wave_kernel
             xa[mt][kc] = (ok && c < p.Cin) ? *reinterpret_cast<const f32x4*>(src + kc * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    // validity of the 4 * NMT pixels this lane's accumulator rows cover (the reference zero-pads the EXPANDED activation)
-    unsigned vmask[(NMT + 7) / 8] = {0};     // bit (mt % 8) * 4 + r of word mt / 8
+    // validity of the NMT pixels this lane's accumulators cover (the reference zero-pads the EXPANDED activation).  The
+    // expand weights are the A operand of the MFMAs, so the accumulators are channel-major: a lane holds channels
+    // 4 (lane >> 4) .. + 3 of pixel 16 mt + (lane & 15) and writes them to the E tile as one 16-byte piece.
+    unsigned vmask = 0;                          // bit mt
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int px = mt * 16 + (lane >> 4) * 4 + r;
-            const int iy = iy0 + px / IW;
-            int ix = ix0 + px % IW;
-            if (p.circular) { if (ix < 0) ix += p.W; else if (ix >= p.W) ix -= p.W; }
-            const bool ok = px < NIP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            vmask[mt >> 3] |= (ok ? 1u : 0u) << ((mt & 7) * 4 + r);
-        }
+    for (int mt = 0; mt < NMT; ++mt) {
+        const int px = mt * 16 + (lane & 15);
+        const int iy = iy0 + px / IW;
+        int ix = ix0 + px % IW;
+        if (p.circular) { if (ix < 0) ix += p.W; else if (ix >= p.W) ix -= p.W; }
+        const bool ok = px < NIP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        vmask |= (ok ? 1u : 0u) << mt;
+    }
     const int q = lane & 3, slot = lane >> 2;    // depthwise: channel quad q of the chunk, output slot (16 slots x OPL outputs)
     for (int ch0 = 0; ch0 < p.mid; ch0 += 16) {
         // ---- expand: E[px][n] = swish(sum_c X[px][c] We[ch0 + n][c] + be) for the NIP input pixels ----
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64, KCH == 1 ? 3 : 2) void mbconv_front_wave_kernel
 #pragma unroll
         for (int kc = 0; kc < KCH; ++kc)
             wfrag[kc] = *reinterpret_cast<const f32x4*>(p.we + (size_t)(ch0 + (lane & 15)) * CP + kc * 16 + 4 * (lane >> 4));
-        const float be = p.be[ch0 + (lane & 15)];
+        const f32x4 be = *reinterpret_cast<const f32x4*>(p.be + ch0 + 4 * (lane >> 4));
         // four m-tiles at a time: four independent accumulator chains hide the 40-cycle dependent-MFMA latency
 #pragma unroll
         for (int mt0 = 0; mt0 < NMT; mt0 += 4) {
@@ -251,17 +251,16 @@ __global__ __launch_bounds__(64, KCH == 1 ? 3 : 2) void mbconv_front_wave_kernel
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (mt0 + u < NMT) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[mt0 + u][kc][e], wfrag[kc][e], acc[u], 0, 0, 0);
+                        if (mt0 + u < NMT) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[kc][e], xa[mt0 + u][kc][e], acc[u], 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int mt = mt0 + u;
                 if (mt >= NMT) continue;
+                const float keep = (float)((vmask >> mt) & 1u);   // a multiply, not a branch around the swish
+                f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int px = mt * 16 + (lane >> 4) * 4 + r;          // rows >= NIP land in the sink rows
-                    const float keep = (float)((vmask[mt >> 3] >> ((mt & 7) * 4 + r)) & 1u);   // a multiply, not a branch around the swish
-                    Es[px * ES2 + (lane & 15)] = swish_f(acc[u][r] + be) * keep;
-                }
+                for (int r = 0; r < 4; ++r) v[r] = swish_f(acc[u][r] + be[r]) * keep;
+                *reinterpret_cast<f32x4*>(Es + (mt * 16 + (lane & 15)) * ES2 + 4 * (lane >> 4)) = v;   // rows >= NIP: sink rows
             }
         }
         __builtin_amdgcn_s_waitcnt(0);

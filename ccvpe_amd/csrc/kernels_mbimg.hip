@@ -92,24 +92,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
 #define CCVPE_MI_LOAD_A(set_, mt_)                                                                               \
     _Pragma("unroll") for (int kc = 0; kc < KCH; ++kc)                                                           \
         abuf[set_][kc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (mt_) < NMT ? a_lane + (unsigned)(mt_) * a_mt : 0x80000000u, kc * 64, 0));
-    // one m-tile: 4 KCH dependent MFMAs (the SIMD's other wave fills the dependent-issue gaps), bias + swish, scatter
+    // one m-tile: 4 KCH dependent MFMAs (the SIMD's other wave fills the dependent-issue gaps; the expand weights are the A
+    // operand, so a lane ends up with 4 consecutive channels of ONE pixel), bias + swish, one 16-byte scatter per lane
 #define CCVPE_MI_SCATTER(acc_, mt_)                                                                              \
     {                                                                                                            \
-        const int4 po = *reinterpret_cast<const int4*>(ptab + (mt_) * 16 + (lane >> 4) * 4);                     \
-        const int pos[4] = {po.x, po.y, po.z, po.w};                                                             \
-        float v[4];                                                                                              \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) { v[r] = swish_i(acc_[r] + be); Es[pos[r] + (lane & 15)] = v[r]; } \
-        if (p.circular) {                                                                                        \
-            const int4 dd = *reinterpret_cast<const int4*>(dtab + (mt_) * 16 + (lane >> 4) * 4);                 \
-            const int dds[4] = {dd.x, dd.y, dd.z, dd.w};                                                         \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) Es[dds[r] + (lane & 15)] = v[r];                       \
-        }                                                                                                        \
+        const int pos = ptab[(mt_) * 16 + (lane & 15)];                                                          \
+        f32x4 v;                                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = swish_i(acc_[r] + be[r]);                           \
+        *reinterpret_cast<f32x4*>(Es + pos + 4 * (lane >> 4)) = v;                                               \
+        if (p.circular) *reinterpret_cast<f32x4*>(Es + dtab[(mt_) * 16 + (lane & 15)] + 4 * (lane >> 4)) = v;   \
     }
 #define CCVPE_MI_MTILE(set_, mt_)                                                                                \
     {                                                                                                            \
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};                                                                        \
         _Pragma("unroll") for (int kc = 0; kc < KCH; ++kc)                                                       \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[set_][kc][e], wf[kc][e], acc, 0, 0, 0); \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kc][e], abuf[set_][kc][e], acc, 0, 0, 0); \
         CCVPE_MI_SCATTER(acc, mt_);                                                                              \
     }
 
@@ -156,7 +153,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
         // depthwise taps and bias of this chunk -> LDS (read after the barrier below)
         if (tap_thread) *reinterpret_cast<f32x4*>(wks + (tid >> 2) * 16 + (tid & 3) * 4) = tapv;
         if (bias_thread) bds[tid - (NT - 16)] = biasv;
-        const float be = p.be[ch0 + (lane & 15)];
+        const f32x4 be = *reinterpret_cast<const f32x4*>(p.be + ch0 + 4 * (lane >> 4));   // channel-major accumulators: 4 channels of one pixel per lane
 
         // ---- expand: m-tiles wave, wave + NWV, ...; set 0 holds the first one already ----
         for (int mt = wave; mt < NMT;) {
