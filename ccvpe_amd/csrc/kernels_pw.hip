@@ -101,10 +101,11 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p) {
 #pragma unroll
                     for (int t = 0; t < TN; ++t) {
                         const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + t * 16 * ldb + ks * 16);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[j].x, bv.x, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[j].y, bv.y, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[j].z, bv.z, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[j].w, bv.w, acc[t], 0, 0, 0);
+                        // weights as the A operand: channel-major accumulators (4 consecutive columns of ONE row per lane)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.x, acur[j].x, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.y, acur[j].y, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.z, acur[j].z, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.w, acur[j].w, acc[t], 0, 0, 0);
                     }
                 }
             }
@@ -115,10 +116,18 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p) {
         // ---- epilogue: bias + activation -> wave-private C patch -> 16-byte row pieces ----
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
-            const int n = n0 + t * 16 + (lane & 15);
-            const float bias = n < p.N ? p.bias[n] : 0.f;
+            const int n = n0 + t * 16 + kq4;
+            f32x4 v;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cw[(kq4 + i) * LDC + t * 16 + (lane & 15)] = apply_act(acc[t][i] + bias, p.act);
+            for (int i = 0; i < 4; ++i) v[i] = acc[t][i] + (n + i < p.N ? p.bias[n + i] : 0.f);
+            if (p.act == ACT_SWISH) {            // uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], ACT_SWISH);
+            } else if (p.act == ACT_RELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(cw + (lane & 15) * LDC + t * 16 + kq4) = v;
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
