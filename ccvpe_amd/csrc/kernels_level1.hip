@@ -137,20 +137,33 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
                 const float* ap0 = Xs + min(mt0 * 16 + (lane & 15), XT * XT - 1) * XS + 4 * (lane >> 4);
                 const float* ap1 = Xs + min(mt1 * 16 + (lane & 15), XT * XT - 1) * XS + 4 * (lane >> 4);
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                if (mt1 < 7) {
 #pragma unroll
-                for (int kc = 0; kc < KCH_MAX; ++kc) {
-                    if (kc >= kch) break;
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap0 + kc * 16);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap1 + kc * 16);
-                    const f32x4 w = wd[kc];
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a0.x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a1.x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a0.y, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a1.y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a0.z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a1.z, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a0.w, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a1.w, acc1, 0, 0, 0);
+                    for (int kc = 0; kc < KCH_MAX; ++kc) {
+                        if (kc >= kch) break;
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap0 + kc * 16);
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap1 + kc * 16);
+                        const f32x4 w = wd[kc];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a0.x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a1.x, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a0.y, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a1.y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a0.z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a1.z, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a0.w, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a1.w, acc1, 0, 0, 0);
+                    }
+                } else {   // the seventh m-tile has no partner: one chain
+#pragma unroll
+                    for (int kc = 0; kc < KCH_MAX; ++kc) {
+                        if (kc >= kch) break;
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap0 + kc * 16);
+                        const f32x4 w = wd[kc];
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, a0.x, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, a0.y, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, a0.z, acc0, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, a0.w, acc0, 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
