@@ -169,8 +169,9 @@ def test_reload_state_dict_changes_result():
     assert not torch.allclose(a, b)
     m.load_state_dict(weights.generate_state_dict("oxford", cfg["seed"]))
     c = m(g, s)[0]
-    # re-ingesting the weights re-tunes the per-layer tiles, which may change the summation order
-    assert (a - c).abs().max().item() <= 2e-5 * a.abs().max().item()
+    # re-ingesting the weights re-tunes the per-layer tiles, which may change the summation order and swap Winograd F(4x4)
+    # (1.4e-5 of scale per layer) for another form on a layer: 1e-4 of scale
+    assert (a - c).abs().max().item() <= 1e-4 * a.abs().max().item()
 
 
 @pytest.mark.parametrize("name", ["vigor_prior180_circ", "kitti", "oxford"])
