@@ -1453,7 +1453,7 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
                 *op.tile = cfg;
                 op.fn(c);   // warm-up (also sets the dynamic-LDS attribute on first use)
                 float ms = 1e30f;
-                for (int trial = 0; trial < 2; ++trial) {   // min of two timed pairs: one noisy sample must not pick the tile
+                for (int trial = 0; trial < 3; ++trial) {   // min of three timed pairs: one noisy sample must not pick the tile
                     HIPCHK(hipEventRecord(e0, nullptr));
                     op.fn(c);
                     op.fn(c);
