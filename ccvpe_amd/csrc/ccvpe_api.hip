@@ -1437,12 +1437,13 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
             static const bool no_split = getenv("CCVPE_TUNE_SPLITK") && std::atoi(getenv("CCVPE_TUNE_SPLITK")) == 0;
             // the persistent Winograd grids also try odd split factors: 160 work items on 256 resident workgroups (conv6.0) are
             // 3 rounds of quarter items with split 4 but 2 rounds of thirds with split 3
-            static const int SPLITS[] = {1, 2, 3, 4, 5, 6, 8, 12, 16};
+            static const int SPLITS[] = {1, 255, 2, 3, 4, 5, 6, 8, 12, 16};   // 255: F(4x4) tail split (kernels_wino4.hip); before the rest, whose limits end the loop
             for (int split : SPLITS) {
                 if (split > 1 && no_split) break;
+                if (split == 255 && !conv_igemm_tile_is_wino4(t)) continue;
                 if (split > 1 && (split & (split - 1)) && !conv_igemm_tile_is_wino(t)) continue;
                 if (split > 1 && conv_igemm_tile_is_pw(t)) break;   // the pointwise persistent tiles keep K whole
-                if (split > 1) {   // split-K only where the grid underfills the chip and K is deep enough
+                if (split > 1 && split != 255) {   // split-K only where the grid underfills the chip and K is deep enough
                     // (the persistent Winograd grid also splits when the tile count is an awkward multiple of the
                     // 512 resident workgroups: 640 tiles = 1.25 per workgroup, 4 x 640 quarter-tiles = 5 each)
                     const bool wino = conv_igemm_tile_is_wino(t);
@@ -1452,6 +1453,7 @@ static int autotune_plan(ccvpe_handle h, Plan& pl) {
                 const int cfg = t | (split << 8);
                 *op.tile = cfg;
                 op.fn(c);   // warm-up (also sets the dynamic-LDS attribute on first use)
+                if (split == 255 && (conv_igemm_last_tile() >> 8) != 255) continue;   // tail split not applicable to this grid
                 float ms = 1e30f;
                 for (int trial = 0; trial < 3; ++trial) {   // min of three timed pairs: one noisy sample must not pick the tile
                     HIPCHK(hipEventRecord(e0, nullptr));
@@ -1664,7 +1666,8 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
                 double issued = op.flops;   // launches that are not tiled GEMMs: issued == algorithmic
                 if (tile) {
                     nm += std::string("|") + conv_igemm_tile_name(tile);
-                    if ((tile >> 8) > 1) nm += "_splitk" + std::to_string(tile >> 8);
+                    if ((tile >> 8) == 255) nm += "_tailsplit";
+                    else if ((tile >> 8) > 1) nm += "_splitk" + std::to_string(tile >> 8);
                     // FLOPs the launch puts on the matrix pipe: M and N padded to the tile, K to the packed depth;
                     // Winograd F(2x2,3x3): 16 products per 2x2 output tile and channel pair; bf16x3: three MFMAs per product
                     ConvParams q{};
@@ -1875,7 +1878,8 @@ int ccvpe_debug_dump_plan(ccvpe_handle h, const char* path) {
         const Op& op = pl->ops[i];
         std::fprintf(f, "op %zu %s stream=%d wait=%d signal=%d tile=%s", i, op.name.c_str(), op.stream, op.wait_on.empty() ? -1 : op.wait_on[0], (int)op.signal,
                      op.tile ? conv_igemm_tile_name(*op.tile & 0xff) : "-");
-        if (op.tile && (*op.tile >> 8) > 1) std::fprintf(f, "_splitk%d", *op.tile >> 8);
+        if (op.tile && (*op.tile >> 8) == 255) std::fprintf(f, "_tailsplit");
+        else if (op.tile && (*op.tile >> 8) > 1) std::fprintf(f, "_splitk%d", *op.tile >> 8);
         for (int id : op.uses) std::fprintf(f, " t%d[off=%zu,n=%zu]=%016llx", id, pl->off[id], pl->size[id], sums[id]);
         std::fprintf(f, "\n");
     }
@@ -1930,7 +1934,8 @@ int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Ci
     p.dst[0] = {out, Cout, 0}; p.ndst = 1;
     hipStream_t st = (hipStream_t)stream;
     if (((tile >> 8) & 0xff) > 1) {   // tile word = id | (split-K << 8): give the launch a slab
-        const size_t fl = (size_t)((tile >> 8) & 0xff) * p.M * p.N;
+        const int sk = (tile >> 8) & 0xff;
+        const size_t fl = (size_t)(sk == 255 ? 8 : sk) * p.M * p.N;   // 255 = F(4x4) tail split: its slab is a fraction of 8 full ones
         void* d = nullptr;
         if (hipMalloc(&d, fl * sizeof(float)) != hipSuccess) { cleanup(); return fail(CCVPE_ENOMEM, "split-K slab"); }
         tmp.dev_allocs.push_back(d);

@@ -83,6 +83,7 @@ struct ConvParams {
     // Winograd F(2x2,3x3) form of a 3x3 / stride 1 / pad 1 layer (kernels_wino.hip); null = not packed
     const float* wino_w;       // [Cin/8][16][wino_n16][128]
     int wino_n16;              // ceil(N / 16)
+    int wino_nb, wino_n16_off; // F(4x4) sub-launches: n-blocks this launch covers (0 = all), first 16-channel slice
     unsigned wino_bytes;
     // Winograd F(4x4,3x3) form (kernels_wino4.hip), packed for the wide decoder layers only; null = not packed
     const float* wino4_w;      // [ceil(Cin/16)*4 k-steps][9 xi quads][wino_n16][64 lanes][4]
@@ -112,6 +113,7 @@ bool conv_wino_tile_supported(const ConvParams& p, int tile);   // the form tile
 bool conv_igemm_tile_is_wino4(int tile);
 void launch_wino4_64(const ConvParams& p, hipStream_t s);
 void launch_wino4_128(const ConvParams& p, hipStream_t s);
+bool conv_wino4_tail_applied();
 size_t conv_wino4_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out);
 bool conv_igemm_tile_is_wino(int tile);
 size_t conv_wino_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out, int* n16_out);

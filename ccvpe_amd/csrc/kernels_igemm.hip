@@ -481,13 +481,15 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
         if (p.w_hi == nullptr) return -1;
         if (!conv_igemm_tile_is_bf16x3(tile)) tile = NTILES + 3;   // conv_bf16x3_64x64_m32: valid for any shape
     }
-    if (splitk < 2 || p.partial == nullptr || (size_t)splitk * p.M * p.N > p.partial_floats) splitk = 1;
+    if (splitk == 255) { if (!conv_igemm_tile_is_wino4(tile) || p.partial == nullptr) splitk = 1; }   // F(4x4) tail split: sized by its launcher
+    else if (splitk < 2 || p.partial == nullptr || (size_t)splitk * p.M * p.N > p.partial_floats) splitk = 1;
     p.splitk = splitk;
     g_last_tile = tile | (splitk << 8);
     if (tile <= NTILES) TILES[tile - 1].launch(p, s);
     else if (conv_igemm_tile_is_pw(tile)) pw_tile(pw_index(tile))->launch(p, s);
     else if (conv_igemm_tile_is_wino(tile)) wino_tile(tile - NTILES - bf16x3_num_tiles() - 1)->launch(p, s);
     else (*bf16x3_tile(tile - NTILES - 1)).launch(p, s);
+    if (splitk == 255 && !conv_wino4_tail_applied()) g_last_tile = tile | (1 << 8);   // the tail split did not apply: a plain launch
     return 0;
 }
 

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     const int mbx = p.W >> 4, mby = p.H >> 4;
     const int mblocks = p.B * mbx * mby;
-    const int total = mblocks * ((p.wino_n16 + NW - 1) / NW);
+    const int total = mblocks * (p.wino_nb ? p.wino_nb : (p.wino_n16 + NW - 1) / NW);   // wino_nb: a sub-launch over some n-blocks
 
     // persistent work loop (see kernels_wino.hip): XCD x owns a contiguous run of items, channel block slowest
     const int xcd = blockIdx.x & 7;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // weights: [k-step][xi/4][n16 slice][lane][xi%4], one 16-byte load per (k-step, quad)
     const unsigned w_quad_b = (unsigned)p.wino_n16 * 1024u;      // bytes between consecutive quads
     const unsigned w_step_b = w_quad_b * 9u;                     // bytes per k-step
-#define CCVPE_W4_WBASE(nb_) ((nb_) * NW + wave < p.wino_n16 ? (unsigned)((nb_) * NW + wave) * 1024u + (unsigned)lane * 16u : OOB)
+#define CCVPE_W4_WBASE(nb_) ((nb_) * NW + wave + p.wino_n16_off < p.wino_n16 ? (unsigned)((nb_) * NW + wave + p.wino_n16_off) * 1024u + (unsigned)lane * 16u : OOB)
     unsigned w_base = CCVPE_W4_WBASE(nb);
 
     // split-K over channel groups (blockIdx.z)
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 template <int NW>
-static void launch_wino4(const ConvParams& p_in, hipStream_t s) {
+static void launch_wino4_plain(const ConvParams& p_in, hipStream_t s) {
     ConvParams p = p_in;
     if (p.splitk > 1) {   // never launch an empty K slice (it would leave its slab unwritten): 84 groups over 16 slices = 14 x 6
         const int ngr = (p.Cin + W4_GCH - 1) / W4_GCH;
@@ -360,11 +360,47 @@ static void launch_wino4(const ConvParams& p_in, hipStream_t s) {
     auto kern = conv_wino4_kernel<NW>;
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     const int mblocks = p.B * (p.W >> 4) * (p.H >> 4);
-    const int nblocks = (p.wino_n16 + NW - 1) / NW;
+    const int nblocks = p.wino_nb ? p.wino_nb : (p.wino_n16 + NW - 1) / NW;
     const int resident = (NW == 4 ? 2 : 1) * 256 / (p.splitk > 1 ? p.splitk : 1);   // 256-thread workgroups: two per CU, 512-thread: one
     dim3 grid(std::min(mblocks * nblocks, std::max(resident, 8)), 1, p.splitk > 1 ? p.splitk : 1);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
     if (p.splitk > 1) launch_splitk_reduce(p, s);
+}
+
+// cfg split code 255 = "tail split": when the work items are a whole number of rounds of the resident workgroups plus a
+// remainder that is a whole number of n-blocks (conv5.0: 128 pixel blocks x 5 channel blocks = 640 items on 512 workgroups),
+// the full rounds run unsplit and only the remaining n-blocks are split over K - 1.3 rounds of work instead of 2, and only
+// their slice of the output goes through slabs.
+static thread_local bool g_tail_applied = false;
+bool conv_wino4_tail_applied() { return g_tail_applied; }   // did the last F(4x4) launch of this thread with split code 255 split its tail?
+
+template <int NW>
+static void launch_wino4(const ConvParams& p, hipStream_t s) {
+    g_tail_applied = false;
+    if (p.splitk != 255) { launch_wino4_plain<NW>(p, s); return; }
+    ConvParams a = p;
+    a.splitk = 1;
+    const int mblocks = p.B * (p.W >> 4) * (p.H >> 4);
+    const int nblocks = (p.wino_n16 + NW - 1) / NW;
+    const int resident = (NW == 4 ? 2 : 1) * 256;
+    const int rem = (mblocks * nblocks) % resident;
+    const int ngr = (p.Cin + W4_GCH - 1) / W4_GCH;
+    const int tail_nb = mblocks > 0 ? rem / mblocks : 0;
+    int split = tail_nb > 0 ? std::min(resident / rem, ngr / 2) : 0;
+    const int n0 = (nblocks - tail_nb) * NW * 16;                    // first channel of the tail
+    if (rem == 0 || rem % mblocks != 0 || tail_nb >= nblocks || split < 2 || p.partial == nullptr ||
+        (size_t)split * p.M * (size_t)(p.N - n0) > p.partial_floats || (n0 & 3) != 0) {
+        launch_wino4_plain<NW>(a, s);
+        return;
+    }
+    g_tail_applied = true;
+    a.wino_nb = nblocks - tail_nb;
+    launch_wino4_plain<NW>(a, s);
+    ConvParams b = p;
+    b.wino_nb = tail_nb; b.wino_n16_off = (nblocks - tail_nb) * NW;
+    b.N = p.N - n0; b.bias = p.bias + n0; b.dst[0].coff = p.dst[0].coff + n0;
+    b.splitk = split;
+    launch_wino4_plain<NW>(b, s);
 }
 
 void launch_wino4_64(const ConvParams& p, hipStream_t s) { launch_wino4<4>(p, s); }

@@ -131,6 +131,27 @@ def test_winograd_split_k(shape, splitk):
         assert err <= (1e-4 if "wino4" in name else 2e-5), f"tile {name} split-K {splitk}: {err:.3g}"
 
 
+def test_winograd_tail_split():
+    """cfg split code 255 of the F(4x4,3x3) tiles: 2 x 16 x 128 pixels = 16 pixel blocks x 33 channel blocks of 64 = 528 work items on
+    512 resident workgroups -> 512 run whole, the last channel block (16 items) is split over K through slabs (the same grid
+    arithmetic as conv5.0 at batch 32: 640 items); the 128-channel form has no whole-block remainder and runs unsplit."""
+    lib = _lib.load()
+    B, H, W, Cin, Cout = 2, 16, 128, 64, 2112
+    g = torch.Generator(device="cuda").manual_seed(77)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    for act in (0, 1):
+        ref = ref_conv(x, w, b, 1, 1, act)
+        for t in range(1, lib.ccvpe_op_num_tiles() + 1):
+            name = lib.ccvpe_op_tile_name(t).decode()
+            if "wino4" not in name:
+                continue
+            out, _ = _lib.op_conv2d(x, w, b, 1, 1, act, t | (255 << 8))
+            err = (out - ref).abs().max().item() / ref.abs().max().item()
+            assert err <= 1e-4, f"tile {name} tail split act {act}: {err:.3g}"
+
+
 PW_SHAPES = [
     # B, H, W, Cin, Cout: 1x1 layers of the encoders (expand / project / head shapes, ragged M and N, K tails)
     (2, 16, 16, 16, 96), (1, 19, 23, 40, 240), (3, 8, 8, 112, 672), (2, 16, 16, 480, 80), (1, 16, 16, 24, 144), (2, 5, 7, 328, 40),
