@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64, KCH == 1 ? 3 : 2) void mbconv_front_wave_kernel
                 *reinterpret_cast<f32x4*>(Es + (mt * 16 + (lane & 15)) * ES2 + 4 * (lane >> 4)) = v;   // rows >= NIP: sink rows
             }
         }
-        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only: LDS traffic of this wave is done; global loads / stores stay in flight
         __builtin_amdgcn_wave_barrier();
         // ---- depthwise K x K from the E tile, BN + swish, store, pooling partial ----
         const int c = ch0 + q * 4;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64, KCH == 1 ? 3 : 2) void mbconv_front_wave_kernel
 #pragma unroll
             for (int e = 0; e < 4; ++e) pool[e] += __shfl_xor(pool[e], off);
         if (slot == 0) *reinterpret_cast<f32x4*>(p.pool + ((size_t)b * gridDim.x + tile) * p.mid + c) = pool;
-        __builtin_amdgcn_s_waitcnt(0);       // the E tile is rewritten by the next chunk's expand
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the E tile is rewritten by the next chunk's expand (the output stores stay in flight)
         __builtin_amdgcn_wave_barrier();
     }
 }

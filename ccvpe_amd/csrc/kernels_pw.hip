@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p) {
             }
             *reinterpret_cast<f32x4*>(cw + (lane & 15) * LDC + t * 16 + kq4) = v;
         }
-        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only: LDS traffic of this wave is done; global loads / stores stay in flight
         __builtin_amdgcn_wave_barrier();
         constexpr int C4 = BN / 4;
         for (int it = lane; it < 16 * C4; it += 64) {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p) {
             const int m = mt * 16 + row, n = n0 + c4 * 4;
             if (m < p.M && n < p.N) emit_out4(p, m, n, *reinterpret_cast<const f32x4*>(cw + row * LDC + c4 * 4));
         }
-        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only: LDS traffic of this wave is done; global loads / stores stay in flight
         __builtin_amdgcn_wave_barrier();
         mt += mt_stride;
     }
