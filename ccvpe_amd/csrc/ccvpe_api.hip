@@ -711,7 +711,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         mp.we = bw.exp_lin; mp.be = bw.expand.bias; mp.wd = bw.dw_w; mp.bd = bw.dw_b;
         mp.k = b.k; mp.s = b.s; mp.pad_t = lo; mp.pad_l = lo; mp.circular = circular; mp.OH = oh; mp.OW = ow;
         // small-spatial blocks: the whole expanded image of 16 channels lives in LDS (kernels_mbimg.hip); CCVPE_FUSE_MBCONV=0 / CCVPE_MBCONV_IMAGE=0 turn it off
-        static const bool image_off = getenv("CCVPE_MBCONV_IMAGE") && std::atoi(getenv("CCVPE_MBCONV_IMAGE")) == 0;
+        const bool image_off = getenv("CCVPE_MBCONV_IMAGE") && std::atoi(getenv("CCVPE_MBCONV_IMAGE")) == 0;   // read per plan: tests toggle it
         const bool image = b.e != 1 && bw.exp_lin != nullptr && h->fuse_mbconv != 0 && !image_off && mbconv_image_supported(mp);
         const bool fused = image || (b.e != 1 && bw.exp_lin != nullptr && mbconv_front_supported(b.k, b.s, b.cin, mid) &&
                            (h->fuse_mbconv == 2 || (h->fuse_mbconv == 1 && mbconv_front_profitable(b.k))));
