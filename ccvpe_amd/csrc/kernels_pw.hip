@@ -158,7 +158,7 @@ static void launch_pw2(const ConvParams& p, hipStream_t s) {
     const int mtiles = (p.M + 15) / 16;
     const int nblocks = (p.N + BN - 1) / BN;
     const int wgs_needed = (mtiles + 3) / 4;
-    const int per_cu = std::max(1, std::min(4, (int)(150 * 1024 / lds)));            // workgroups that fit a CU's LDS
+    const int per_cu = std::max(1, std::min(5, (int)(150 * 1024 / lds)));            // workgroups that fit a CU's LDS
     const int gx = std::max(1, std::min(wgs_needed, (256 * per_cu + nblocks - 1) / nblocks));
     hipLaunchKernelGGL(kern, dim3(gx, nblocks), dim3(256), lds, s, p);
 }
