@@ -329,6 +329,42 @@ def main() -> int:
         torch.cuda.empty_cache()
         return r
 
+    def pipeline_run(m, n=20, warm=3):
+        """The whole on-device test loop for one batch (the counterpart of train_VIGOR.py:265-326): decoded uint8 images (1024 x 2048
+        panoramas, 640 x 640 aerial tiles, VIGOR's native sizes) -> PIL-exact resize + ToTensor + Normalize + roll (ccvpe_preprocess_resize)
+        -> forward -> argmax / orientation lookup -> ground-truth metrics (ccvpe_eval_metrics) -> gather of the compact results."""
+        from ccvpe_amd import _lib
+        B = args.batch
+        gen = torch.Generator().manual_seed(17)
+        pano = torch.randint(0, 256, (B, 1024, 2048, 3), dtype=torch.uint8, generator=gen).to(dev)
+        tile = torch.randint(0, 256, (B, 640, 640, 3), dtype=torch.uint8, generator=gen).to(dev)
+        shift = torch.randint(0, 640, (B,), dtype=torch.int32, generator=gen).to(dev)
+        gt_index = torch.randint(0, 512 * 512, (B,), dtype=torch.int32, generator=gen).to(dev)
+        ang = torch.rand(B, generator=gen) * 6.2831853
+        gt_cs = torch.stack([torch.cos(ang), torch.sin(ang)], dim=1).to(dev)
+        mpp = 0.113248 / 512 * 640     # train_VIGOR.py:301-308 (NewYork)
+
+        def st():
+            gg = _lib.preprocess_resize(pano, (320, 640), shift=shift)
+            ss = _lib.preprocess_resize(tile, (512, 512))
+            outs = m(gg, ss)
+            ev = m.evaluate(outs[1], outs[2], gt_index, mpp, gt_cos_sin=gt_cs)
+            rows = torch.stack([ev["index"].to(torch.float32), ev["meter_distance"].to(torch.float32), ev["prob_at_gt"].to(torch.float32),
+                                ev["orientation_error_deg"].to(torch.float32), ev["angle_pred_deg"].to(torch.float32)], dim=1)
+            return D.gather_results(rows)
+        for _ in range(warm):
+            st()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(n):
+            r = st()
+        torch.cuda.synchronize(dev)
+        d = time.perf_counter() - t
+        assert r.shape == (B, 5) and bool(torch.isfinite(r).all())
+        return {"queries_per_s": n * B / d, "ms_per_step": 1e3 * d / n, "steps": n, "batch": B,
+                "stages": "uint8 1024x2048 + 640x640 (HBM resident) -> preprocess_resize -> forward -> postprocess -> eval_metrics -> gather",
+                "input_bytes_per_query": 1024 * 2048 * 3 + 640 * 640 * 3}
+
     if rank == 0:
         peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         # ---- roofline of the dominant kernel: one extra profiled step, hipEvents around every launch ----
@@ -339,23 +375,38 @@ def main() -> int:
             gr = groups.setdefault(tag, [0.0, 0.0, 0.0, 0, 0.0])
             gr[0] += ms; gr[1] += fl; gr[2] += by; gr[3] += 1; gr[4] += iss
         total_ms = sum(v[0] for v in groups.values())
-        mfma = {k: v for k, v in groups.items() if k.startswith(("conv_igemm", "conv_bf16x3", "conv_wino"))}
+        # tiled GEMM / Winograd launches (tag = tile name) - the candidates for the dominant kernel ...
+        mfma = {k: v for k, v in groups.items() if k.startswith(("conv_igemm", "conv_bf16x3", "conv_wino", "conv_pw"))}
         dom = max(mfma, key=lambda k: mfma[k][0])
         ms, fl, by, cnt, iss = mfma[dom]
-        all_ms = sum(v[0] for v in mfma.values())
-        all_fl = sum(v[1] for v in mfma.values())
-        all_iss = sum(v[4] for v in mfma.values())
+        # ... and every launch whose arithmetic runs on the matrix cores: + the fused last decoder level (level1_kernel), the fused
+        # MBConv fronts (expand GEMM + depthwise) and the MFMA rolling match of the wide levels
+        def on_matrix_cores(tag):
+            return tag in mfma or tag in ("fused", "expand_dw") or tag in ("match1", "match2", "match3", "match4")
+        allm = {k: v for k, v in groups.items() if on_matrix_cores(k)}
+        all_ms = sum(v[0] for v in allm.values())
+        all_fl = sum(v[1] for v in allm.values())
+        all_iss = sum(v[4] for v in allm.values())
+        # the most time-consuming launch group that is NOT on the matrix cores: the HBM-side entry of the roofline
+        hbm = {k: v for k, v in groups.items() if not on_matrix_cores(k) and v[2] > 0}
+        hdom = max(hbm, key=lambda k: hbm[k][0]) if hbm else None
         traffic, traffic_alg, traffic_src = traffic_from_profiles(dom)
         line["roofline"] = {
             "kernel": dom, "bound": "mfma", "launches_per_step": cnt,
             "achieved": iss / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
             "frac": iss / (ms * 1e-3) / 1e12 / peak,
-            "achieved_is": "FLOPs issued on the matrix pipe (tile padding included; Winograd F(2x2,3x3) = 16 products per 2x2 tile and channel pair)",
+            "achieved_is": "FLOPs issued on the matrix pipe (tile padding included; Winograd F(4x4,3x3) tiles = 36 products per 4x4 output tile and channel pair, F(2x2,3x3) = 16 per 2x2 tile: a quarter / 4 ninths of the direct-convolution count in algorithmic_tflops)",
             "algorithmic_tflops": fl / (ms * 1e-3) / 1e12,
             "avg_launch_ms": ms / cnt, "issued_flops_per_launch": iss / cnt, "algorithmic_flops_per_launch": fl / cnt,
             "traffic": traffic, "traffic_algorithmic": traffic_alg, "traffic_source": traffic_src,
             "all_mfma_kernels": {"issued_tflops": all_iss / (all_ms * 1e-3) / 1e12, "frac": all_iss / (all_ms * 1e-3) / 1e12 / peak,
                                  "algorithmic_tflops": all_fl / (all_ms * 1e-3) / 1e12, "share_of_serial_step": all_ms / total_ms},
+            "hbm_bound": None if hdom is None else {
+                "kernel": hdom, "bound": "hbm", "launches_per_step": hbm[hdom][3], "ms_per_step": hbm[hdom][0],
+                "algorithmic_bytes_per_step": hbm[hdom][2], "achieved": hbm[hdom][2] / (hbm[hdom][0] * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": hbm[hdom][2] / (hbm[hdom][0] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "note": "most time-consuming launch group off the matrix cores; algorithmic bytes (each tensor once) over the hipEvent time; "
+                        "8 TB/s spec, ~6.3 TB/s achievable (MI355X_MICROARCH.md); PMC FETCH/WRITE sizes per kernel: profiles/r03_hbm_kernels.md"},
             "serial_step_ms": total_ms,
             "end_to_end": {"gflop_per_query": GFLOP_PER_QUERY[args.workload],
                            "algorithmic_tflops": line["value"] / world * GFLOP_PER_QUERY[args.workload] / 1e3,
@@ -373,6 +424,8 @@ def main() -> int:
             # BASELINE.json metric asks batch 1 AND 32; BASELINE.md section 5 lists configs 3-5
             line["batch1"] = latency_run(model, grd[:1].contiguous(), sat[:1].contiguous())
             line["batch1"]["note"] = "same model, batch 1, hipGraph replay; latency = one synchronised step (forward + post-processing)"
+            if variant.startswith("vigor") and fov == 360.0:
+                line["pipeline"] = pipeline_run(model)
         del model
         torch.cuda.empty_cache()
         if extras and not args.no_extra:

@@ -37,6 +37,9 @@ SYMBOLS = [
     ("ccvpe_finalize_weights", C.c_int, [C.c_void_p]),
     ("ccvpe_save_packed", C.c_int, [C.c_void_p, C.c_char_p]),
     ("ccvpe_load_packed", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("ccvpe_import_tuning", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("ccvpe_export_tuning", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("ccvpe_tuning_generation", C.c_int, [C.c_void_p]),
     ("ccvpe_max_micro_batch", C.c_int, [C.c_int32, C.c_float, C.c_int32, C.c_int32]),
     ("ccvpe_output_channels", C.c_int, [C.c_void_p, C.c_int32]),
     ("ccvpe_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
@@ -144,6 +147,20 @@ def op_conv2d(x_nhwc, w, bias=None, stride=1, pad=0, act=0, tile=0, iters=0):
     return out, (ms.value if iters > 0 else None)
 
 _lib = None
+
+
+def library_digest() -> str:
+    """Digest of the library that load() binds: the in-tree sources, or the file CCVPE_LIB_PATH names."""
+    override = os.environ.get("CCVPE_LIB_PATH")
+    if override:
+        import hashlib
+        h = hashlib.sha256()
+        with open(override, "rb") as fh:
+            for chunk in iter(lambda: fh.read(1 << 20), b""):
+                h.update(chunk)
+        return h.hexdigest()
+    from . import build as _build
+    return _build._digest()
 
 
 def load() -> C.CDLL:

@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libccvpe_hip.so")
 STAMP = os.path.join(CSRC, ".libccvpe_hip.stamp")
-SOURCES = ["ccvpe_api.hip", "kernels_igemm.hip", "kernels_igemm_bf16x3.hip", "kernels_wino.hip", "kernels_wino4.hip", "kernels_encoder.hip", "kernels_match.hip", "kernels_tail.hip", "kernels_level1.hip", "kernels_mbconv.hip", "kernels_preproc.hip", "kernels_pw.hip", "kernels_mbimg.hip"]
-HEADERS = ["kernels.h", "igemm_common.h", os.path.join("..", "..", "include", "ccvpe.h")]
+SOURCES = ["ccvpe_api.hip", "ccvpe_weights.hip", "ccvpe_plan.hip", "ccvpe_tune.hip", "kernels_igemm.hip", "kernels_igemm_bf16x3.hip", "kernels_wino.hip", "kernels_wino4.hip", "kernels_wino4p.hip", "kernels_wino4x.hip", "kernels_encoder.hip", "kernels_match.hip", "kernels_tail.hip", "kernels_level1.hip", "kernels_mbconv.hip", "kernels_preproc.hip", "kernels_pw.hip", "kernels_mbimg.hip"]
+HEADERS = ["kernels.h", "igemm_common.h", "ccvpe_internal.h", os.path.join("..", "..", "include", "ccvpe.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 # Per-file flags.  kernels_match.hip: hipcc's SLP vectoriser fuses the dot-product and norm accumulators of match_kernel
 # into v_pk_fma_f32 ... op_sel:[0,1,0]; on gfx950 a packed fp32 instruction whose LOW result takes the HIGH half of src1
@@ -27,7 +27,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # kernels_wino4.hip: the SLP vectoriser packs the Winograd transforms into v_pk_fma_f32 / v_pk_add_f32 plus ~50 v_mov_b32 per
 # pass to pair the operands; beside fp32 MFMAs every vector instruction costs issue time (tools/ubench_fill.hip), so the scalar
 # form (fewer instructions, no moves) is the faster one.
-EXTRA_FLAGS = {"kernels_match.hip": ["-fno-slp-vectorize"], "kernels_wino4.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"kernels_match.hip": ["-fno-slp-vectorize"], "kernels_wino4.hip": ["-fno-slp-vectorize"], "kernels_wino4p.hip": ["-fno-slp-vectorize"], "kernels_wino4x.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

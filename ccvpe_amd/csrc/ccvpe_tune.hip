@@ -1,0 +1,203 @@
+// Per-layer tile selection of libccvpe_hip.so: every tiled launch of a plan is timed with each candidate (tile, split-K)
+// on the plan's own buffers; the choices are kept in a tuning table that can be exported / imported as text, so a later
+// process (or another rank) runs exactly the same launches without measuring again.  No reference counterpart.
+#include "ccvpe_internal.h"
+
+
+// ---- tuning table -----------------------------------------------------------------------------------------------
+// One entry per tiled launch, keyed by everything that shapes it: variant, roll count, padding mode, precision, batch, launch
+// name, GEMM shape and which kernel families may serve it - so the decoder launches of a full forward, of a cached-aerial
+// forward and of a debug plan share their entries, and a switch that changes a layer's shape or eligibility gives another
+// key.  Tiles are stored by NAME: a table survives library builds that renumber or add tiles.
+std::string tuning_key(ccvpe_handle_s* h, const Plan& pl, const Op& op) {
+    char buf[256];
+    std::snprintf(buf, sizeof(buf), "v%d_r%d_c%d_p%d_b%d|%s|%dx%dx%d|%d%d%d%d", h->cfg.variant, h->rolls[1], h->cfg.circular_padding,
+                  h->cfg.reserved[0], pl.B, op.name.c_str(), op.gemm_m, op.gemm_n, op.gemm_kpad, op.wino_ok ? 1 : 0, op.wino4_ok ? 1 : 0,
+                  op.is_pw ? 1 : 0, op.bf16x3_only ? 1 : 0);
+    if (op.wino4x_ok) std::strcat(buf, "x");
+    return buf;
+}
+
+static int tile_by_name(const std::string& name) {
+    if (name == "auto") return 0;
+    for (int t = 1; t <= conv_igemm_num_tiles(); ++t)
+        if (name == conv_igemm_tile_name(t)) return t;
+    return -1;
+}
+
+// Applies the table to the plan's launches; returns how many launches it does not cover (those keep TILE_AUTO and are measured).
+static int apply_tuning(ccvpe_handle_s* h, Plan& pl, std::vector<bool>& known) {
+    int missing = 0;
+    known.assign(pl.ops.size(), false);
+    for (size_t i = 0; i < pl.ops.size(); ++i) {
+        Op& op = pl.ops[i];
+        if (!op.tile) continue;
+        int t = -1, split = 0;
+        if (h->tuning_lookup) {
+            auto e = h->tuning.find(tuning_key(h, pl, op));
+            if (e != h->tuning.end()) { t = tile_by_name(e->second.first); split = e->second.second; }
+        }
+        if (t < 0) { ++missing; continue; }
+        *op.tile = t | (split << 8);
+        known[i] = true;
+    }
+    return missing;
+}
+
+static void record_tuning(ccvpe_handle_s* h, const Plan& pl) {
+    for (const auto& op : pl.ops) {
+        if (!op.tile) continue;
+        const int cfg = *op.tile;
+        h->tuning[tuning_key(h, pl, op)] = {(cfg & 0xff) ? conv_igemm_tile_name(cfg & 0xff) : "auto", (cfg >> 8) & 0xff};
+    }
+}
+
+extern "C" {
+
+/* text form: one "op <key> <tile name> <split code>" line per launch; '#' lines are comments */
+int ccvpe_import_tuning(ccvpe_handle h, const char* text) {
+    if (!h || !text) return ccvpe_fail(CCVPE_EINVAL, "null argument");
+    int n = 0;
+    const char* p = text;
+    while (*p) {
+        const char* e = std::strchr(p, '\n');
+        const std::string line(p, e ? (size_t)(e - p) : std::strlen(p));
+        p = e ? e + 1 : p + line.size();
+        char a[256], b[256];
+        int split = 0;
+        if (std::sscanf(line.c_str(), "op %255s %255s %d", a, b, &split) == 3 && split >= 0 && split <= 255) { h->tuning[a] = {b, split}; ++n; }
+        else if (!line.empty() && line[0] != '#') return ccvpe_fail(CCVPE_EINVAL, "tuning table: cannot parse '%s'", line.c_str());
+    }
+    return n;
+}
+
+int ccvpe_export_tuning(ccvpe_handle h, char* buf, size_t capacity, size_t* needed) {
+    if (!h) return ccvpe_fail(CCVPE_EINVAL, "null handle");
+    std::string out;
+    for (const auto& op : h->tuning) out += "op " + op.first + " " + op.second.first + " " + std::to_string(op.second.second) + "\n";
+    if (needed) *needed = out.size() + 1;
+    if (!buf || capacity < out.size() + 1) return buf ? ccvpe_fail(CCVPE_EINVAL, "tuning table needs %zu bytes", out.size() + 1) : 0;
+    std::memcpy(buf, out.c_str(), out.size() + 1);
+    return 0;
+}
+
+int ccvpe_tuning_generation(ccvpe_handle h) { return h ? h->tuned_plans : ccvpe_fail(CCVPE_EINVAL, "null handle"); }
+
+}  // extern "C"
+
+// Per-layer tile selection by measurement: every tiled launch of the plan is timed with each candidate tile (hipEvents) on the
+// plan's own buffers, filled with unit-variance random data - on zeros the chip holds a ~19 % higher clock and pipe-bound
+// candidates are mis-ranked against memory-bound ones (MI355X_MICROARCH.md, DVFS) - and the fastest is kept.  Runs once per
+// plan that the tuning table does not know, before its first forward.
+int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
+    Ctx c;
+    c.arena = h->arena; c.off = &pl.off; c.stream = nullptr;
+    pl.set_scratch(c, 0);
+    if (pl.tune_cache.id >= 0) c.cache_out = c.ptr(pl.tune_cache);
+    // the candidates run on the null stream inside the shared arena: earlier forwards of this handle may still be in flight
+    // on a non-blocking caller stream or on the internal second stream (neither is ordered with the null stream)
+    HIPCHK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    launch_fill_random(h->arena, pl.total, 0x9e3779b9u, nullptr);
+    const int nt = conv_igemm_num_tiles();
+    for (size_t oi = 0; oi < pl.ops.size(); ++oi) {
+        Op& op = pl.ops[oi];
+        if (!op.tile || (known && (*known)[oi])) continue;   // launches the tuning table covers are not measured
+        ConvParams q{};
+        q.M = op.gemm_m; q.N = op.gemm_n;
+        int best = 0;
+        float best_ms = 1e30f;
+        const int nkt = op.gemm_kpad / 32;
+        for (int t = 1; t <= nt; ++t) {
+            if (conv_igemm_tile_util(q, t) < 0.45) continue;
+            if (conv_igemm_tile_is_bf16x3(t) && (h->cfg.reserved[0] != 1 || getenv("CCVPE_TUNE_NO_BF16X3"))) continue;
+            if (const char* only = getenv("CCVPE_TUNE_BF16_ONLY"))   // diagnostic: keep only bf16x3 tiles whose name contains the string
+                if (conv_igemm_tile_is_bf16x3(t) && !std::strstr(conv_igemm_tile_name(t), only)) continue;
+            if (op.bf16x3_only && !conv_igemm_tile_is_bf16x3(t)) continue;
+            if (conv_igemm_tile_is_wino(t) && !op.wino_ok) continue;
+            if (conv_igemm_tile_is_wino4x(t)) { if (!op.wino4x_ok || conv_igemm_tile_wino4x_cfg(t) != conv_wino4x_config(op.gemm_n)) continue; }
+            else if (conv_igemm_tile_is_wino4(t) && !op.wino4_ok) continue;
+            static const bool prefer_pw = getenv("CCVPE_TUNE_PREFER_PW") != nullptr;   // test hook: pointwise tiles wherever they apply
+            if (prefer_pw && op.is_pw && !op.bf16x3_only && !conv_igemm_tile_is_pw(t) && op.gemm_kpad <= 512) continue;
+            if (conv_igemm_tile_is_pw(t)) {
+                ConvParams qq{}; qq.M = 16; qq.N = 1 << 20;
+                const int bn = (int)(((long long)qq.N) / conv_igemm_tile_blocks(qq, t));   // the tile's column width
+                if (!op.is_pw || op.bf16x3_only || !conv_pw_fits(bn, op.gemm_kpad) || getenv("CCVPE_NO_PW")) continue;
+            }
+            const long long blocks = conv_igemm_tile_blocks(q, t);
+            static const bool no_split = getenv("CCVPE_TUNE_SPLITK") && std::atoi(getenv("CCVPE_TUNE_SPLITK")) == 0;
+            // the persistent Winograd grids also try odd split factors: 160 work items on 256 resident workgroups (conv6.0) are
+            // 3 rounds of quarter items with split 4 but 2 rounds of thirds with split 3
+            static const int SPLITS[] = {1, 255, 2, 3, 4, 5, 6, 8, 12, 16};   // 255: F(4x4) tail split (kernels_wino4.hip); before the rest, whose limits end the loop
+            for (int split : SPLITS) {
+                if (split > 1 && no_split) break;
+                if (split == 255 && (!conv_igemm_tile_is_wino4(t) || conv_igemm_tile_is_wino4x(t))) continue;
+                if (split > 1 && (split & (split - 1)) && !conv_igemm_tile_is_wino(t)) continue;
+                if (split > 1 && conv_igemm_tile_is_pw(t)) break;   // the pointwise persistent tiles keep K whole
+                if (split > 1 && split != 255) {   // split-K only where the grid underfills the chip and K is deep enough
+                    // (the persistent Winograd grid also splits when the tile count is an awkward multiple of the
+                    // 512 resident workgroups: 640 tiles = 1.25 per workgroup, 4 x 640 quarter-tiles = 5 each)
+                    const bool wino = conv_igemm_tile_is_wino(t);
+                    if (blocks >= (wino ? 2048 : 512) || blocks * split > (wino ? 8192 : 2048) || nkt < 4 * split) break;
+                    if ((size_t)split * op.gemm_m * op.gemm_n > Plan::SPLITK_FLOATS) break;
+                }
+                const int cfg = t | (split << 8);
+                *op.tile = cfg;
+                op.fn(c);   // warm-up (also sets the dynamic-LDS attribute on first use)
+                if (split == 255 && (conv_igemm_last_tile() >> 8) != 255) continue;   // tail split not applicable to this grid
+                float ms = 1e30f;
+                for (int trial = 0; trial < 3; ++trial) {   // min of three timed pairs: one noisy sample must not pick the tile
+                    HIPCHK(hipEventRecord(e0, nullptr));
+                    op.fn(c);
+                    op.fn(c);
+                    HIPCHK(hipEventRecord(e1, nullptr));
+                    HIPCHK(hipEventSynchronize(e1));
+                    float t = 0.f;
+                    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+                    ms = std::min(ms, t);
+                }
+                if (ms < best_ms) { best_ms = ms; best = cfg; }
+            }
+        }
+        *op.tile = best;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(hipDeviceSynchronize());   // ... and the forward that follows may be issued on such a stream
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ccvpe_fail(CCVPE_EHIP, "autotune launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int get_plan(ccvpe_handle_s* h, int B, int gh, int gw, Plan** out, int mode) {
+    for (auto& p : h->plans)
+        if (p->B == B && p->gh == gh && p->gw == gw && p->mode == mode && (mode == 1 || p->debug == h->debug)) { *out = p.get(); return 0; }
+    auto pl = std::make_unique<Plan>();
+    int rc = build_plan(h, *pl, B, gh, gw, mode);
+    if (rc) return rc;
+    if (pl->total > h->arena_floats) {
+        // growing the arena is the only synchronising step; it happens on the first call per shape
+        HIPCHK(hipDeviceSynchronize());
+        if (h->arena) HIPCHK(hipFree(h->arena));
+        h->arena = nullptr;
+        for (auto& q : h->plans)   // captured graphs point into the old arena
+            if (q->exec) { (void)hipGraphExecDestroy(q->exec); q->exec = nullptr; q->runs = 0; }
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, pl->total * sizeof(float));
+        if (e != hipSuccess) { h->arena_floats = 0; return ccvpe_fail(CCVPE_ENOMEM, "workspace of %zu bytes: %s", pl->total * sizeof(float), hipGetErrorString(e)); }
+        h->arena = (float*)d;
+        h->arena_floats = pl->total;
+    }
+    std::vector<bool> known;
+    if (apply_tuning(h, *pl, known) > 0 && h->autotune) {
+        int rc2 = autotune_plan(h, *pl, &known);
+        if (rc2) return rc2;
+        record_tuning(h, *pl);
+        h->tuned_plans++;
+    }
+    *out = pl.get();
+    h->plans.push_back(std::move(pl));
+    return 0;
+}

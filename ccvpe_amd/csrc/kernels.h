@@ -88,6 +88,13 @@ struct ConvParams {
     // Winograd F(4x4,3x3) form (kernels_wino4.hip), packed for the wide decoder layers only; null = not packed
     const float* wino4_w;      // [ceil(Cin/16)*4 k-steps][9 xi quads][wino_n16][64 lanes][4]
     unsigned wino4_bytes;
+    // xi-split F(4x4) form for layers of <= 128 output channels (kernels_wino4x.hip); null = not packed
+    const float* wino4x_w;     // [k-step][wave][16-byte load][64 lanes][4]
+    unsigned wino4x_bytes;
+    int wino4x_cfg;            // configuration index the weights were packed for (conv_wino4x_config(N))
+    // split F(4x4) form (kernels_wino4p.hip): per-stream scratch for the pre-transformed input V = B^T d B (null = unavailable)
+    float* wino4_v;
+    size_t wino4_v_floats;
 };
 
 // tile = 0 picks automatically from (M, N); otherwise one of the TILE_* ids.
@@ -104,7 +111,7 @@ void launch_splitk_reduce(const ConvParams& p, hipStream_t s);
 struct Bf16x3Tile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); };
 int bf16x3_num_tiles();
 const Bf16x3Tile* bf16x3_tile(int i);
-struct WinoTile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); int f; };   // f: output tile edge, 2 or 4
+struct WinoTile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); int f; bool pre; int xcfg; };   // f: output tile edge, 2 or 4; pre: split form (V pre-transformed); xcfg >= 0: xi-split configuration
 int wino_num_tiles();
 const WinoTile* wino_tile(int i);
 bool conv_wino_supported(const ConvParams& p);
@@ -114,6 +121,17 @@ bool conv_igemm_tile_is_wino4(int tile);
 void launch_wino4_64(const ConvParams& p, hipStream_t s);
 void launch_wino4_128(const ConvParams& p, hipStream_t s);
 bool conv_wino4_tail_applied();
+void launch_wino4p_64(const ConvParams& p, hipStream_t s);    // split form: input transform kernel + matrix kernel
+void launch_wino4p_128(const ConvParams& p, hipStream_t s);
+bool conv_wino4p_tail_applied();
+bool conv_wino4p_supported(const ConvParams& p);
+bool conv_igemm_tile_is_wino4p(int tile);
+bool conv_igemm_tile_is_wino4x(int tile);
+int conv_igemm_tile_wino4x_cfg(int tile);   // xi-split configuration of the tile, -1 for other tiles
+void launch_wino4x(const ConvParams& p, hipStream_t s);       // xi-split form (kernels_wino4x.hip)
+bool conv_wino4x_supported(const ConvParams& p);
+int conv_wino4x_config(int N);
+size_t conv_wino4x_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out, int* cfg_out);
 size_t conv_wino4_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out);
 bool conv_igemm_tile_is_wino(int tile);
 size_t conv_wino_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out, int* n16_out);
@@ -300,6 +318,7 @@ struct MetricsOut { double pixel_distance, meter_distance, prob_at_gt, angle_pre
 void launch_metrics(const PoseOut* pose, const float* heat, int B, int W, int n, const int* gt_index, const float* gt_cos_sin,
                     const double* meter_per_pixel, const double* heading_deg, MetricsOut* out, hipStream_t s);
 
+void launch_fill_random(float* p, size_t n, uint32_t seed, hipStream_t s);   // ~N(0,1) floats (autotune operands)
 void launch_nhwc_to_nchw(const float* in, int in_ld, int coff, int C, int B, int HW, float* out, hipStream_t s);
 
 }  // namespace ccvpe

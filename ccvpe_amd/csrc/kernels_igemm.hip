@@ -345,8 +345,14 @@ bool conv_igemm_tile_is_wino(int tile) { tile &= 0xff; return tile > NTILES + bf
 static int pw_index(int tile) { return (tile & 0xff) - NTILES - bf16x3_num_tiles() - wino_num_tiles() - 1; }
 bool conv_igemm_tile_is_pw(int tile) { const int i = pw_index(tile); return i >= 0 && i < pw_num_tiles(); }
 bool conv_igemm_tile_is_wino4(int tile) { return conv_igemm_tile_is_wino(tile) && wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->f == 4; }
+bool conv_igemm_tile_is_wino4p(int tile) { return conv_igemm_tile_is_wino4(tile) && wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->pre; }
+static int wino4x_cfg_of(int tile) { return conv_igemm_tile_is_wino(tile) ? wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->xcfg : -1; }
+bool conv_igemm_tile_is_wino4x(int tile) { return wino4x_cfg_of(tile) >= 0; }
+int conv_igemm_tile_wino4x_cfg(int tile) { return wino4x_cfg_of(tile); }
 bool conv_wino_tile_supported(const ConvParams& p, int tile) {
     if (!conv_igemm_tile_is_wino(tile)) return false;
+    if (conv_igemm_tile_is_wino4x(tile)) return conv_wino4x_supported(p) && p.wino4x_cfg == wino4x_cfg_of(tile);
+    if (conv_igemm_tile_is_wino4p(tile)) return conv_wino4p_supported(p);
     return conv_igemm_tile_is_wino4(tile) ? conv_wino4_supported(p) : conv_wino_supported(p);
 }
 bool conv_igemm_tile_is_bf16x3(int tile) { tile &= 0xff; return tile > NTILES && tile <= NTILES + bf16x3_num_tiles(); }
@@ -481,7 +487,7 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
         if (p.w_hi == nullptr) return -1;
         if (!conv_igemm_tile_is_bf16x3(tile)) tile = NTILES + 3;   // conv_bf16x3_64x64_m32: valid for any shape
     }
-    if (splitk == 255) { if (!conv_igemm_tile_is_wino4(tile) || p.partial == nullptr) splitk = 1; }   // F(4x4) tail split: sized by its launcher
+    if (splitk == 255) { if (!conv_igemm_tile_is_wino4(tile) || conv_igemm_tile_is_wino4x(tile) || p.partial == nullptr) splitk = 1; }   // F(4x4) tail split: sized by its launcher
     else if (splitk < 2 || p.partial == nullptr || (size_t)splitk * p.M * p.N > p.partial_floats) splitk = 1;
     p.splitk = splitk;
     g_last_tile = tile | (splitk << 8);
@@ -489,7 +495,7 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
     else if (conv_igemm_tile_is_pw(tile)) pw_tile(pw_index(tile))->launch(p, s);
     else if (conv_igemm_tile_is_wino(tile)) wino_tile(tile - NTILES - bf16x3_num_tiles() - 1)->launch(p, s);
     else (*bf16x3_tile(tile - NTILES - 1)).launch(p, s);
-    if (splitk == 255 && !conv_wino4_tail_applied()) g_last_tile = tile | (1 << 8);   // the tail split did not apply: a plain launch
+    if (splitk == 255 && !(conv_igemm_tile_is_wino4p(tile) ? conv_wino4p_tail_applied() : conv_wino4_tail_applied())) g_last_tile = tile | (1 << 8);   // the tail split did not apply: a plain launch
     return 0;
 }
 

@@ -6,6 +6,8 @@
 // acos-sign rule (train_VIGOR.py:297-311).
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace ccvpe {
 
 // thread = one output pixel; 9 taps x 16 channels = 4 float4 per tap, NHWC input (64 B per pixel).
@@ -323,6 +325,28 @@ __global__ void nhwc_to_nchw_kernel(const float* in, int in_ld, int coff, int C,
         const int b = (int)(t / C);
         out[i] = in[((size_t)b * HW + p) * in_ld + coff + c];
     }
+}
+
+// Unit-variance pseudo-random floats (sum of three uniforms on [-1, 1): the autotuner's operands - timing candidates on
+// zeros ranks them at a clock the real data never sees).  Counter-based (PCG hash of the element index): any grid gives the same bits.
+__global__ __launch_bounds__(256) void fill_random_kernel(float* __restrict__ p, size_t n, uint32_t seed) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float acc = 0.f;
+        uint32_t st = (uint32_t)i * 747796405u + (uint32_t)(i >> 32) * 2891336453u + seed;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            st = st * 747796405u + 2891336453u;
+            uint32_t w = ((st >> ((st >> 28u) + 4u)) ^ st) * 277803737u;
+            w = (w >> 22u) ^ w;
+            acc += (float)(w >> 8) * (2.0f / 16777216.0f) - 1.0f;
+        }
+        p[i] = acc;
+    }
+}
+void launch_fill_random(float* p, size_t n, uint32_t seed, hipStream_t s) {
+    if (n == 0) return;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(fill_random_kernel, dim3(blocks), dim3(256), 0, s, p, n, seed);
 }
 
 void launch_nhwc_to_nchw(const float* in, int in_ld, int coff, int C, int B, int HW, float* out, hipStream_t s) {

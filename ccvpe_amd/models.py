@@ -18,7 +18,7 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import _lib, spec
+from . import _lib, spec, tuning
 
 __all__ = ["CVM_VIGOR", "CVM_VIGOR_ori_prior", "CVM_KITTI", "CVM_OxfordRobotCar"]
 
@@ -153,6 +153,8 @@ class _CVMBase(nn.Module):
             self._handle, self._handle_device = h, index
             self._weights_dirty = True
             self._rolls = tuple(lib.ccvpe_output_channels(h, k) for k in range(6))
+            tuning.load_into(lib, h)     # committed table + this machine's cache: known plans are not measured again
+            self._tune_gen = lib.ccvpe_tuning_generation(h)
             if self._debug:
                 _lib.check(lib.ccvpe_set_debug(h, 1), "ccvpe_set_debug")
             if getattr(self, "_n_streams", 2) != 2:
@@ -175,10 +177,27 @@ class _CVMBase(nn.Module):
                     torch.cuda.synchronize(dev)
                 _lib.check(lib.ccvpe_finalize_weights(self._handle), "ccvpe_finalize_weights")
                 self.last_weight_source = "state_dict"
-                if cache_file:
-                    os.makedirs(os.path.dirname(cache_file), exist_ok=True)
-                    _lib.check(lib.ccvpe_save_packed(self._handle, cache_file.encode()), "ccvpe_save_packed")
+                if cache_file:   # best effort: a lost race or a read-only directory costs the re-pack on the next start only
+                    try:
+                        os.makedirs(os.path.dirname(cache_file), exist_ok=True)
+                        if lib.ccvpe_save_packed(self._handle, cache_file.encode()) != 0:
+                            import warnings
+                            warnings.warn(f"ccvpe_amd: packed-weight cache not written: {(lib.ccvpe_last_error() or b'').decode()}")
+                    except OSError as e:
+                        import warnings
+                        warnings.warn(f"ccvpe_amd: packed-weight cache not written: {e}")
             self._weights_dirty = False
+
+    def _tuning_sync(self) -> None:
+        """After a call that may have built a plan: write the tuning table back when this handle has measured a new one."""
+        gen = _lib.load().ccvpe_tuning_generation(self._handle)
+        if gen != getattr(self, "_tune_gen", 0):
+            self._tune_gen = gen
+            tuning.save_from(_lib.load(), self._handle)
+
+    def export_tuning(self) -> str:
+        """Text of this handle's tuning table (plans loaded at start plus plans measured since)."""
+        return tuning.export(_lib.load(), self._handle) if self._handle is not None else ""
 
     def _cache_path(self, sd) -> str:
         """File name of the packed weights of this exact state dict: content hash of every float tensor in key order,
@@ -195,8 +214,11 @@ class _CVMBase(nn.Module):
                 continue
             hsh.update(key.encode())
             hsh.update(t.detach().cpu().contiguous().numpy().tobytes())
-        from . import build as _build
-        tag = f"{self._variant}-{self._precision}-{int(self.circular_padding)}-{_build._digest()[:16]}-{hsh.hexdigest()[:32]}"
+        # switches that change what the packer emits are part of the key, and so is the library actually loaded
+        sw = "".join(f"{k}={os.environ[k]};" for k in ("CCVPE_NO_WINO4", "CCVPE_WINO4_MIN_N", "CCVPE_WINOGRAD") if k in os.environ)
+        if sw:
+            hsh.update(sw.encode())
+        tag = f"{self._variant}-{self._precision}-{int(self.circular_padding)}-{_lib.library_digest()[:16]}-{hsh.hexdigest()[:32]}"
         return os.path.join(self._weight_cache, tag + ".ccvpepack")
 
     # ---- forward ----------------------------------------------------------------------------
@@ -240,6 +262,7 @@ class _CVMBase(nn.Module):
             rc = _lib.load().ccvpe_forward(self._handle, C.c_void_p(grd.data_ptr()), grd.shape[2], grd.shape[3],
                                            C.c_void_p(sat.data_ptr()), B, C.byref(out), C.c_void_p(stream))
         _lib.check(rc, "ccvpe_forward")
+        self._tuning_sync()
         return tensors
 
     # ---- aerial-side caching for streaming -------------------------------
@@ -259,6 +282,7 @@ class _CVMBase(nn.Module):
         stream = torch.cuda.current_stream(sat.device).cuda_stream
         _lib.check(lib.ccvpe_encode_aerial(self._handle, C.c_void_p(sat.data_ptr()), B, C.c_void_p(cache.data_ptr()),
                                            C.c_void_p(stream)), "ccvpe_encode_aerial")
+        self._tuning_sync()
         cache._ccvpe_batch = B
         return cache
 
@@ -278,6 +302,7 @@ class _CVMBase(nn.Module):
         rc = _lib.load().ccvpe_forward_cached(self._handle, C.c_void_p(grd.data_ptr()), grd.shape[2], grd.shape[3],
                                               C.c_void_p(cache.data_ptr()), B, C.byref(out), C.c_void_p(stream))
         _lib.check(rc, "ccvpe_forward_cached")
+        self._tuning_sync()
         return tensors
 
     # ---- extras beyond the reference surface ------------------------------------------------
@@ -361,6 +386,7 @@ class _CVMBase(nn.Module):
         n = lib.ccvpe_profile_forward(self._handle, C.c_void_p(grd.data_ptr()), grd.shape[2], grd.shape[3],
                                       C.c_void_p(sat.data_ptr()), B, C.byref(out), C.c_void_p(stream))
         _lib.check(n, "ccvpe_profile_forward")
+        self._tuning_sync()
         rows = []
         name = C.create_string_buffer(128)
         ms, fl, by, iss = C.c_float(), C.c_double(), C.c_double(), C.c_double()

@@ -119,6 +119,17 @@ int ccvpe_finalize_weights(ccvpe_handle h);
 int ccvpe_save_packed(ccvpe_handle h, const char* path);
 int ccvpe_load_packed(ccvpe_handle h, const char* path);
 
+/* Tuning table.  The first forward of a new (batch, ground size) measures every tiled launch of its plan with each candidate
+ * kernel tile and keeps the fastest (1-2 s at batch 32); the choices are the only thing about a forward that can differ between
+ * two processes.  ccvpe_export_tuning writes them as text (one "op <launch key> <tile name> <split>" line per launch; call with
+ * buf = NULL to get the size in *needed), ccvpe_import_tuning loads such text (returns the number of entries read): a launch
+ * found in the table is not measured again and runs exactly as recorded, so two handles with the same table produce
+ * bit-identical results.  ccvpe_tuning_generation counts the plans this handle has measured launches of (the host side saves
+ * the table when it grows; see ccvpe_amd/tuning.py).  No reference counterpart. */
+int ccvpe_import_tuning(ccvpe_handle h, const char* text);
+int ccvpe_export_tuning(ccvpe_handle h, char* buf, size_t capacity, size_t* needed);
+int ccvpe_tuning_generation(ccvpe_handle h);
+
 /* Largest micro_batch whose intermediate tensors all stay below the 2 GiB the kernels address with 32-bit byte offsets
  * (ccvpe_forward refuses a larger one with CCVPE_EINVAL instead of wrapping offsets).  Pure host arithmetic, no device
  * needed.  Negative on a ground size the variant's descriptor heads cannot take. */

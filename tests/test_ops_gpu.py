@@ -69,6 +69,15 @@ def test_every_tile_config_is_correct():
         assert err <= tol, f"tile {t} ({name}): {err:.3g}"
 
 
+X_WIDTHS = [32, 48, 64, 80, 96, 128]     # conv_wino4x_<width>: the xi-split F(4x4) form takes a layer in ONE n-block of its width
+
+
+def x_tile_applies(name, cout):
+    """conv_wino4x_<w> serves exactly the layers whose narrowest fitting configuration it is (24 <= Cout <= w)."""
+    w = int(name.rsplit("_", 1)[1])
+    return cout >= 24 and next((x for x in X_WIDTHS if cout <= x), None) == w
+
+
 WINO_SHAPES = [
     # B, H, W, Cin, Cout
     (1, 16, 16, 8, 16),
@@ -78,6 +87,10 @@ WINO_SHAPES = [
     (1, 32, 48, 104, 20),      # a partly filled last 16-channel slice
     (2, 16, 16, 200, 160),
     (1, 64, 64, 16, 100),
+    (1, 32, 32, 48, 32),       # conv2_ori-shaped: the 32-wide xi-split configuration
+    (2, 16, 32, 88, 64),       # conv3_ori-shaped (64), Cin = 88: a half-filled last 16-channel group
+    (1, 32, 32, 104, 80),      # conv3-shaped: eight waves, 3 + 2 slices
+    (1, 16, 16, 24, 30),       # not a multiple of 4 channels: only the xi-split form (one channel per lane in its epilogue) takes it
 ]
 
 
@@ -98,7 +111,11 @@ def test_winograd_tiles_match_torch(shape):
         for t in tiles:
             name = lib.ccvpe_op_tile_name(t).decode()
             f4 = "wino4" in name
-            if (f4 and Cout < 40) or Cout % 4:   # F(4x4,3x3) weights are only packed for layers of >= 40 output channels; both forms store 4 channels per lane
+            if "wino4x" in name:
+                refuse = not x_tile_applies(name, Cout)
+            else:
+                refuse = (f4 and Cout < 40) or Cout % 4 != 0   # F(4x4,3x3) weights are only packed for layers of >= 40 output channels; both forms store 4 channels per lane
+            if refuse:
                 with pytest.raises(_lib.CcvpeError):
                     _lib.op_conv2d(x, w, b, 1, 1, act, t)
                 continue
@@ -109,7 +126,7 @@ def test_winograd_tiles_match_torch(shape):
             assert err <= (1e-4 if f4 else 2e-5), f"tile {name} act {act}: {err:.3g}"
 
 
-@pytest.mark.parametrize("shape,splitk", [((2, 16, 16, 200, 160), 2), ((1, 32, 48, 104, 100), 4), ((3, 16, 16, 64, 88), 2),
+@pytest.mark.parametrize("shape,splitk", [((2, 16, 16, 200, 160), 2), ((1, 32, 48, 104, 100), 4), ((3, 16, 16, 64, 88), 2), ((1, 16, 16, 104, 40), 3),
                                           # more slices than equal shares fill: 5 / 3 groups of 16 channels, 10 / 5 chunks of 8 over 4 slices
                                           ((1, 16, 16, 80, 64), 4), ((1, 16, 16, 40, 64), 4), ((2, 16, 16, 1344, 64), 16)])
 def test_winograd_split_k(shape, splitk):
@@ -124,7 +141,7 @@ def test_winograd_split_k(shape, splitk):
     ref = ref_conv(x, w, b, 1, 1, 1)
     for t in range(1, lib.ccvpe_op_num_tiles() + 1):
         name = lib.ccvpe_op_tile_name(t).decode()
-        if "wino" not in name:
+        if "wino" not in name or ("wino4x" in name and not x_tile_applies(name, Cout)):
             continue
         out, _ = _lib.op_conv2d(x, w, b, 1, 1, 1, t | (splitk << 8))
         err = (out - ref).abs().max().item() / ref.abs().max().item()
@@ -145,7 +162,7 @@ def test_winograd_tail_split():
         ref = ref_conv(x, w, b, 1, 1, act)
         for t in range(1, lib.ccvpe_op_num_tiles() + 1):
             name = lib.ccvpe_op_tile_name(t).decode()
-            if "wino4" not in name:
+            if "wino4" not in name or "wino4x" in name:
                 continue
             out, _ = _lib.op_conv2d(x, w, b, 1, 1, act, t | (255 << 8))
             err = (out - ref).abs().max().item() / ref.abs().max().item()

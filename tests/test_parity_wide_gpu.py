@@ -12,7 +12,7 @@ import torch
 
 from ccvpe_amd import models, weights
 from tests import golden_util as gu
-from tests.test_parity_gpu import build_model, inputs
+from tests.test_parity_gpu import build_model, inputs, ori_weighted_error, raw_ori_magnitude
 
 pytestmark = pytest.mark.gpu
 
@@ -89,8 +89,10 @@ def test_batch32_properties_configs_3_and_4(name):
         for lvl, period in ((2, 8), (3, 8), (4, 8), (6, 4)):
             t = outs[2 + lvl]
             assert torch.equal(t[:, :period], t[:, period:2 * period]), f"ms{lvl}: channels repeat with period {period}"
+    mag = raw_ori_magnitude(cfg, g, s)
     for i in (0, 13, 31):
         one = m(g[i:i + 1], s[i:i + 1])
+        assert ori_weighted_error(ori[i:i + 1], one[2], mag[i:i + 1]) <= 1e-4, f"sample {i} ori"
         for j, (a, b) in enumerate(zip(outs, one)):
             if j != 2:
                 # batch-1 plans autotune other tiles than batch-32 plans (Winograd F(4x4): 1.4e-5 of scale per layer): 1e-4

@@ -10,6 +10,9 @@ shapes = [tuple(int(v) for v in a.split(",")) for a in args[:k]]
 tiles = [int(v) for v in args[k + 1:]]
 for B, H, W, Cin, Cout in shapes:
     x = torch.randn(B, H, W, Cin, device="cuda")
+    mode = os.environ.get("TT_DATA", "randn")   # relu: half zeros like a post-ReLU activation; zeros: the DVFS best case
+    if mode == "relu": x = x.clamp_min(0)
+    if mode == "zeros": x = torch.zeros_like(x)
     w = torch.randn(Cout, Cin, 3, 3, device="cuda") / (Cin * 9) ** 0.5
     b = torch.randn(Cout, device="cuda")
     for t in tiles:
