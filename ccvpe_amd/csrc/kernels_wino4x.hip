@@ -82,7 +82,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int ROUNDS = (NS + RS - 1) / RS;
     constexpr int RAW_ITEMS = NW == 4 ? 6 : 3;
     constexpr int RAW_HALVES = RAW_ITEMS / 3;
-    constexpr int MX_FLOATS = RS * 36 * 256;               // exchange image of one round: [slice][xi][tile][channel]
+    // NW 4 stages six float4 per thread and group.  EARLY: all six are requested when the group's MFMA phase begins and stored when
+    // it ends (a whole group of cover for the HBM latency under load, 24 registers held); otherwise in two halves of three through
+    // the same 12 registers (the second half requested after the first k-step: one k-step of cover for the first half)
+    constexpr bool EARLY = NW == 4 && S0 <= 3;
+    constexpr int MXQ = 72;                                // floats of one (xi, channel quad): 16 tiles x 4 channels + 8 pad (the readers'
+                                                           // four quads then start on banks 0 / 8 / 16 / 24: conflict-free ds_read_b32)
+    constexpr int MXI = 4 * MXQ;                           // floats per xi
+    constexpr int MX_FLOATS = RS * 36 * MXI;               // exchange image of one round: [slice][xi][channel quad][tile][4]
     constexpr int V_REGION = X4_VFLOATS > MX_FLOATS ? X4_VFLOATS : MX_FLOATS;
     constexpr unsigned OOB = 0x80000000u;
 
@@ -155,12 +162,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (g_begin >= g_end) return;
     const int tail_ks = (p.Cin - (ngr_all - 1) * X4_GCH + 3) >> 2;
 
-    f32x4 raw[3];
+    f32x4 raw[EARLY ? 6 : 3];
     float bq[9 * S0];         // B fragments (weights) of the current k-step, refilled in place for the next one
 #define CCVPE_X4_LOAD_RAW(c0, half)                                                                      \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                    \
         const unsigned o_ = ((c0) + r_ch < p.Cin) ? r_off[3 * (half) + i] : OOB;                         \
-        raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, o_, (c0) * 4, 0)); \
+        raw[(EARLY ? 3 * (half) : 0) + i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, o_, (c0) * 4, 0)); \
     }
 #define CCVPE_X4_STORE_RAW(half)                                                                         \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                    \
@@ -168,7 +175,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if (px_ < 18 * 18) {                                                                             \
             const int py_ = (px_ * 3641) >> 16;                                                          \
             float* d_ = Rs + r_ch * X4_PLANE + py_ * X4_PITCH + (px_ - py_ * 18);                        \
-            d_[0] = raw[i].x; d_[X4_PLANE] = raw[i].y; d_[2 * X4_PLANE] = raw[i].z; d_[3 * X4_PLANE] = raw[i].w; \
+            const f32x4 rv_ = raw[(EARLY ? 3 * (half) : 0) + i];                                         \
+            d_[0] = rv_.x; d_[X4_PLANE] = rv_.y; d_[2 * X4_PLANE] = rv_.z; d_[3 * X4_PLANE] = rv_.w;     \
         }                                                                                                \
     }
 #define CCVPE_X4_LOAD_B(ks, ld_)   /* 16-byte load ld_ of k-step ks (global index): units 4 ld_ .. 4 ld_ + 3 */ \
@@ -257,6 +265,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const int c0n = last_group ? g_begin * X4_GCH : (g + 1) * X4_GCH;
             if (last_group) { CCVPE_X4_ROFF(b_n, by_n, bx_n, have_n); }
             CCVPE_X4_LOAD_RAW(c0n, 0);
+            if (EARLY) { CCVPE_X4_LOAD_RAW(c0n, 1); }
             __builtin_amdgcn_sched_barrier(0);
             // ---- MFMA phase: per k-step 9 xi x S slices; PAR = parity of the quarter (position of xi 9q + xl inside the slots),
             //      S = slices of this wave: both compile-time inside ----
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (RAW_HALVES == 2 && ks == 1) {
+                    if (RAW_HALVES == 2 && !EARLY && ks == 1) {
                         CCVPE_X4_STORE_RAW(0);
                         CCVPE_X4_LOAD_RAW(c0n, 1);
                         __builtin_amdgcn_sched_barrier(0);
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (q & 1) mfma_phase(std::integral_constant<int, 1>{}, std::integral_constant<int, (S1 > 0 ? S1 : 1)>{});
                 else mfma_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, (S1 > 0 ? S1 : 1)>{});
             }
+            if (EARLY) { CCVPE_X4_STORE_RAW(0); }
             CCVPE_X4_STORE_RAW(RAW_HALVES - 1);
             __syncthreads();   // V image free again; next raw patch complete
         }
@@ -325,16 +335,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 for (int e = 0; e < RS; ++e) {
                     const int sg = r * RS + e;
                     if (sg >= NS) continue;
-                    float* mxw = Vs + e * (36 * 256) + ((9 * q) * 16 + wq_tile) * 16 + 4 * wq_cq;
+                    float* mxw = Vs + e * (36 * MXI) + (9 * q) * MXI + wq_cq * MXQ + wq_tile * 4;   // 16 lanes = 256 contiguous bytes
                     if (sg < S0) {
                         if (!hi) {
 #pragma unroll
-                            for (int xl = 0; xl < 9; ++xl) *reinterpret_cast<f32x4*>(mxw + xl * 256) = acc[xl * S0 + sg];
+                            for (int xl = 0; xl < 9; ++xl) *reinterpret_cast<f32x4*>(mxw + xl * MXI) = acc[xl * S0 + sg];
                         }
                     } else if (S1 > 0) {
                         if (hi) {
 #pragma unroll
-                            for (int xl = 0; xl < 9; ++xl) *reinterpret_cast<f32x4*>(mxw + xl * 256) = acc[xl * (S1 > 0 ? S1 : 1) + (sg - S0)];
+                            for (int xl = 0; xl < 9; ++xl) *reinterpret_cast<f32x4*>(mxw + xl * MXI) = acc[xl * (S1 > 0 ? S1 : 1) + (sg - S0)];
                         }
                     }
                 }
@@ -342,11 +352,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const int sg = r * RS + e_sl;
                 const int n = sg * 16 + e_ch;
                 if (sg < NS && n < p.N) {
-                    const float* mx = Vs + e_sl * (36 * 256) + e_tile * 16 + e_ch;
+                    const float* mx = Vs + e_sl * (36 * MXI) + (e_ch >> 2) * MXQ + e_tile * 4 + (e_ch & 3);
                     float tt[4][6];
 #pragma unroll
                     for (int c = 0; c < 6; ++c)
-                        x4_at(mx[(0 * 6 + c) * 256], mx[(1 * 6 + c) * 256], mx[(2 * 6 + c) * 256], mx[(3 * 6 + c) * 256], mx[(4 * 6 + c) * 256], mx[(5 * 6 + c) * 256],
+                        x4_at(mx[(0 * 6 + c) * MXI], mx[(1 * 6 + c) * MXI], mx[(2 * 6 + c) * MXI], mx[(3 * 6 + c) * MXI], mx[(4 * 6 + c) * MXI], mx[(5 * 6 + c) * MXI],
                               tt[0][c], tt[1][c], tt[2][c], tt[3][c]);
                     const float bias = split ? 0.f : p.bias[n];
                     const unsigned o_lane = (unsigned)((((oty * 4) * p.W + otx * 4) * ld + n) * 4);
@@ -403,7 +413,7 @@ static void launch_wino4x_cfg(const ConvParams& p_in, hipStream_t s) {
         const int per = (ngr + p.splitk - 1) / p.splitk;
         p.splitk = (ngr + per - 1) / per;
     }
-    constexpr int mx = (NW / 4) * 36 * 256;
+    constexpr int mx = (NW / 4) * 36 * 4 * 72;
     constexpr size_t lds = ((X4_VFLOATS > mx ? X4_VFLOATS : mx) + X4_GCH * X4_PLANE) * sizeof(float);
     static_assert((NW == 4 ? 2 : 1) * lds <= 160 * 1024, "workgroups per CU");
     static LdsAttr attr;
