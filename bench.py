@@ -170,7 +170,7 @@ def main() -> int:
     def traffic_from_profiles(kernel: str):
         """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (bench.py cannot run
         the profiler on itself; the file names its command): 2*FETCH_SIZE + WRITE_SIZE of one representative launch."""
-        for name in ("r02_traffic.json", "r01_traffic.json"):
+        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     t = json.load(fh)
@@ -388,7 +388,9 @@ def main() -> int:
         all_fl = sum(v[1] for v in allm.values())
         all_iss = sum(v[4] for v in allm.values())
         # the most time-consuming launch group that is NOT on the matrix cores: the HBM-side entry of the roofline
-        hbm = {k: v for k, v in groups.items() if not on_matrix_cores(k) and v[2] > 0}
+        # (groups of launches under 20 us each - squeeze-excite, descriptor heads - are launch-latency bound: listed separately)
+        hbm = {k: v for k, v in groups.items() if not on_matrix_cores(k) and v[2] > 0 and v[0] / v[3] >= 0.02}
+        tiny = {k: v for k, v in groups.items() if not on_matrix_cores(k) and v[0] / v[3] < 0.02}
         hdom = max(hbm, key=lambda k: hbm[k][0]) if hbm else None
         traffic, traffic_alg, traffic_src = traffic_from_profiles(dom)
         line["roofline"] = {
@@ -407,6 +409,7 @@ def main() -> int:
                 "unit": "GB/s", "frac": hbm[hdom][2] / (hbm[hdom][0] * 1e-3) / 1e9 / PEAK_HBM_GBS,
                 "note": "most time-consuming launch group off the matrix cores; algorithmic bytes (each tensor once) over the hipEvent time; "
                         "8 TB/s spec, ~6.3 TB/s achievable (MI355X_MICROARCH.md); PMC FETCH/WRITE sizes per kernel: profiles/r03_hbm_kernels.md"},
+            "latency_bound_launches": {"groups": sorted(tiny), "launches_per_step": sum(v[3] for v in tiny.values()), "ms_per_step": sum(v[0] for v in tiny.values())},
             "serial_step_ms": total_ms,
             "end_to_end": {"gflop_per_query": GFLOP_PER_QUERY[args.workload],
                            "algorithmic_tflops": line["value"] / world * GFLOP_PER_QUERY[args.workload] / 1e3,

@@ -177,9 +177,10 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
     pl.scratch = pl.alloc(1, 1, 1, (int)Plan::SPLITK_FLOATS);
     pl.two_streams = h->two_streams && !h->debug;
     if (pl.two_streams) pl.scratch2 = pl.alloc(1, 1, 1, (int)Plan::SPLITK_FLOATS);
-    if (h->wino && h->cfg.reserved[0] == 0 && !getenv("CCVPE_NO_WINO4P")) {
-        // split Winograd form: room for the largest pre-transformed layer input (36 KiB per 16 x 16 pixel block and 16-channel
-        // group) that stays below 256 MiB - beyond that the extra HBM round trip costs more than the transform it saves
+    if (h->wino && h->cfg.reserved[0] == 0 && getenv("CCVPE_WINO4P")) {
+        // split Winograd form (kernels_wino4p.hip), opt-in: measured equal to or slower than the fused form on every decoder layer
+        // (profiles/r03_wino4_forms.md), so plans neither reserve its scratch nor time its tiles by default.  Room for the largest
+        // pre-transformed layer input (36 KiB per 16 x 16 pixel block and 16-channel group) that stays below 256 MiB
         auto vneed = [&](const DecLevel* lv) {
             size_t best = 0;
             for (int j = 0; j < 5; ++j) {

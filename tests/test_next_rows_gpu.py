@@ -201,3 +201,20 @@ def test_packed_weight_cache_round_trip(tmp_path):
     assert d.last_weight_source == "state_dict"
     for i, (x, y) in enumerate(zip(ref, outs)):
         assert torch.equal(x, y), gu.OUTPUT_NAMES[i]
+
+
+def test_workspace_bytes_of_the_headline_plan_is_bounded():
+    """ccvpe_workspace_bytes: the post-reuse arena of the batch-32 VIGOR plan (DESIGN.md section 3: 3.84 GB incl. two 128 MiB split-K slabs;
+    13 GB before lifetime-based reuse) and its growth with the batch."""
+    import ctypes as C
+    from ccvpe_amd import _lib
+    cfg = gu.CONFIGS["vigor_prior180_circ"]
+    m = models.CVM_VIGOR_ori_prior("cuda", cfg["ori_noise"], cfg["circular"])
+    m.load_state_dict(weights.generate_state_dict(cfg["variant"], cfg["seed"]))
+    m.to("cuda").eval()
+    m._ensure_handle(torch.device("cuda", torch.cuda.current_device()))
+    lib = _lib.load()
+    sizes = {b: lib.ccvpe_workspace_bytes(m._handle, b, 320, 640) for b in (1, 8, 32)}
+    assert 0 < sizes[1] < sizes[8] < sizes[32] < 6 * 1024 ** 3, sizes
+    assert sizes[32] > 2 * 1024 ** 3, sizes       # 32 samples x the 256 x 256 x 96 expanded tensor alone are 0.8 GB
+    assert lib.ccvpe_workspace_bytes(m._handle, 0, 320, 640) == 0      # bad batch: 0 and an error message
