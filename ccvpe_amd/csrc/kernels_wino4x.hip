@@ -62,6 +62,12 @@ __host__ __device__ constexpr int x4_vpos(int xi) {
 __host__ __device__ constexpr int x4_loads(int s) { return (9 * s + 3) / 4; }
 __host__ __device__ constexpr int x4_step_loads(int nw, int s0, int s1) { return 4 * x4_loads(s0) + (nw == 8 ? 4 * x4_loads(s1) : 0); }
 
+#ifndef CCVPE_X4_DEEP
+#define CCVPE_X4_DEEP 1     // dev builds: 0 = one k-step of weight prefetch everywhere
+#endif
+#ifndef CCVPE_X4_SWITCH
+#define CCVPE_X4_SWITCH 0   // dev builds, timing only (wrong results): bit 0 no epilogue, 1 no transform, 2 no raw staging, 3 no MFMAs, 4 no weight refills
+#endif
 #ifndef CCVPE_X4_CLOCK
 #define CCVPE_X4_CLOCK 0   // dev builds (tools/build_variant.sh): 1 = every workgroup stamps s_memtime / s_memrealtime around its work loop
 #endif
@@ -86,6 +92,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // it ends (a whole group of cover for the HBM latency under load, 24 registers held); otherwise in two halves of three through
     // the same 12 registers (the second half requested after the first k-step: one k-step of cover for the first half)
     constexpr bool EARLY = NW == 4 && S0 <= 3;
+    // DEEP: the weights are requested TWO k-steps ahead (two register sets).  vmcnt counts a wave's loads and stores in issue order, so
+    // the first wait for a weight load that is younger than the raw-patch loads (or than the previous tile's output stores) also waits
+    // for those: with one k-step of weight prefetch the HBM latency of the patch was exposed after one k-step whatever the patch's own
+    // prefetch distance (switch experiments: staging 22 %, epilogue 21 % of conv2.0); two k-steps of cover hide most of it.
+    constexpr bool DEEP = CCVPE_X4_DEEP && S0 <= 3;      // (the 64- and 128-channel configurations have no registers left for the second set)
+    constexpr int NBQ = DEEP ? 2 : 1;
     constexpr int MXQ = 72;                                // floats of one (xi, channel quad): 16 tiles x 4 channels + 8 pad (the readers'
                                                            // four quads then start on banks 0 / 8 / 16 / 24: conflict-free ds_read_b32)
     constexpr int MXI = 4 * MXQ;                           // floats per xi
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int tail_ks = (p.Cin - (ngr_all - 1) * X4_GCH + 3) >> 2;
 
     f32x4 raw[EARLY ? 6 : 3];
-    float bq[9 * S0];         // B fragments (weights) of the current k-step, refilled in place for the next one
+    float bq[NBQ][9 * S0];    // B fragments (weights) of the current k-step(s), refilled in place for the k-step NBQ ahead
 #define CCVPE_X4_LOAD_RAW(c0, half)                                                                      \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                    \
         const unsigned o_ = ((c0) + r_ch < p.Cin) ? r_off[3 * (half) + i] : OOB;                         \
@@ -179,13 +191,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             d_[0] = rv_.x; d_[X4_PLANE] = rv_.y; d_[2 * X4_PLANE] = rv_.z; d_[3 * X4_PLANE] = rv_.w;     \
         }                                                                                                \
     }
-#define CCVPE_X4_LOAD_B(ks, ld_)   /* 16-byte load ld_ of k-step ks (global index): units 4 ld_ .. 4 ld_ + 3 */ \
+#define CCVPE_X4_LOAD_B(set_, ks, ld_)   /* 16-byte load ld_ of k-step ks (global index) into register set set_: units 4 ld_ .. 4 ld_ + 3 */ \
     {                                                                                                    \
         const f32x4 t4_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_base, (ks) * w_step_b + (ld_) * 1024u, 0)); \
-        if (4 * (ld_) + 0 < 9 * S0) bq[4 * (ld_) + 0] = t4_.x;                                           \
-        if (4 * (ld_) + 1 < 9 * S0) bq[4 * (ld_) + 1] = t4_.y;                                           \
-        if (4 * (ld_) + 2 < 9 * S0) bq[4 * (ld_) + 2] = t4_.z;                                           \
-        if (4 * (ld_) + 3 < 9 * S0) bq[4 * (ld_) + 3] = t4_.w;                                           \
+        if (4 * (ld_) + 0 < 9 * S0) bq[set_][4 * (ld_) + 0] = t4_.x;                                     \
+        if (4 * (ld_) + 1 < 9 * S0) bq[set_][4 * (ld_) + 1] = t4_.y;                                     \
+        if (4 * (ld_) + 2 < 9 * S0) bq[set_][4 * (ld_) + 2] = t4_.z;                                     \
+        if (4 * (ld_) + 3 < 9 * S0) bq[set_][4 * (ld_) + 3] = t4_.w;                                     \
     }
 
     f32x4 acc[9 * S0];
@@ -194,7 +206,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     CCVPE_X4_LOAD_RAW(g_begin * X4_GCH, 0);
 #pragma unroll
-    for (int l = 0; l < x4_loads(S0); ++l) { CCVPE_X4_LOAD_B(g_begin * 4, l); }
+    for (int l = 0; l < x4_loads(S0); ++l) { CCVPE_X4_LOAD_B(0, g_begin * 4, l); }
+    if (DEEP) {
+#pragma unroll
+        for (int l = 0; l < x4_loads(S0); ++l) { CCVPE_X4_LOAD_B(NBQ - 1, g_begin * 4 + 1, l); }
+    }
     CCVPE_X4_STORE_RAW(0);
     if (RAW_HALVES == 2) {
         CCVPE_X4_LOAD_RAW(g_begin * X4_GCH, 1);
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     }
                 }
             };
-            if (tks >= nks) {
+            if (tks >= nks || (CCVPE_X4_SWITCH & 2)) {
             } else if (NW == 4) {
                 half_item(std::integral_constant<int, 0>{});
                 half_item(std::integral_constant<int, 1>{});
@@ -264,8 +280,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             __syncthreads();   // V image complete; every wave is done with the raw patch
             const int c0n = last_group ? g_begin * X4_GCH : (g + 1) * X4_GCH;
             if (last_group) { CCVPE_X4_ROFF(b_n, by_n, bx_n, have_n); }
-            CCVPE_X4_LOAD_RAW(c0n, 0);
-            if (EARLY) { CCVPE_X4_LOAD_RAW(c0n, 1); }
+            if (!(CCVPE_X4_SWITCH & (4 | 32))) {
+                CCVPE_X4_LOAD_RAW(c0n, 0);
+                if (EARLY) { CCVPE_X4_LOAD_RAW(c0n, 1); }
+            }
             __builtin_amdgcn_sched_barrier(0);
             // ---- MFMA phase: per k-step 9 xi x S slices; PAR = parity of the quarter (position of xi 9q + xl inside the slots),
             //      S = slices of this wave: both compile-time inside ----
@@ -274,34 +292,40 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 constexpr int S = decltype(sc)::value;
                 constexpr int NL = x4_loads(S);
 #pragma unroll 1
-                for (int ks = 0; ks < nks; ++ks) {
-                    const bool last_step = last_group && ks == nks - 1;
-                    const int ksn = last_step ? g_begin * 4 : g * 4 + ks + 1;
-                    const float* va = va0 + ks * (20 * 128);
-                    f32x2 fa[5];
+                for (int ks0 = 0; ks0 < nks; ks0 += NBQ) {   // nks is 2 or 4
 #pragma unroll
-                    for (int s5 = 0; s5 < 5; ++s5) fa[s5] = *reinterpret_cast<const f32x2*>(va + s5 * 128);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int hb = 0; hb < NBQ; ++hb) {
+                        const int ks = ks0 + hb;
+                        int ksn;             // k-step (global index) this set is refilled for: NBQ k-steps ahead in the workgroup's stream
+                        if (ks + NBQ < nks) ksn = g * 4 + ks + NBQ;
+                        else ksn = (last_group ? g_begin : g + 1) * 4 + (ks + NBQ - nks);
+                        const float* va = va0 + ks * (20 * 128);
+                        f32x2 fa[5];
 #pragma unroll
-                    for (int xl = 0; xl < 9; ++xl) {
-                        const float v = ((xl + PAR) & 1) ? fa[(xl + PAR) >> 1].y : fa[(xl + PAR) >> 1].x;
+                        for (int s5 = 0; s5 < 5; ++s5) fa[s5] = *reinterpret_cast<const f32x2*>(va + s5 * 128);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int sl = 0; sl < S; ++sl) {
-                            const int u = xl * S + sl;
-                            // weights as the A operand: D[channel][tile]; a lane ends up with 4 consecutive channels of ONE tile
-                            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[u], v, acc[u], 0, 0, 0);
-                            if ((u & 3) == 3 || u == 9 * S - 1) {   // the units of a 16-byte weight load have issued: refill it for the next k-step
-                                __builtin_amdgcn_sched_barrier(0);
-                                CCVPE_X4_LOAD_B(ksn, u >> 2);
-                                (void)NL;
+                        for (int xl = 0; xl < 9; ++xl) {
+                            const float v = ((xl + PAR) & 1) ? fa[(xl + PAR) >> 1].y : fa[(xl + PAR) >> 1].x;
+#pragma unroll
+                            for (int sl = 0; sl < S; ++sl) {
+                                const int u = xl * S + sl;
+                                // weights as the A operand: D[channel][tile]; a lane ends up with 4 consecutive channels of ONE tile
+                                if (!(CCVPE_X4_SWITCH & 8)) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[hb][u], v, acc[u], 0, 0, 0);
+                                else acc[u][0] += v;
+                                if (((u & 3) == 3 || u == 9 * S - 1) && !(CCVPE_X4_SWITCH & 16)) {   // the units of a 16-byte weight load have issued: refill it
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    CCVPE_X4_LOAD_B(hb, ksn, u >> 2);
+                                    (void)NL;
+                                }
                             }
                         }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (RAW_HALVES == 2 && !EARLY && ks == 1) {
-                        CCVPE_X4_STORE_RAW(0);
-                        CCVPE_X4_LOAD_RAW(c0n, 1);
                         __builtin_amdgcn_sched_barrier(0);
+                        if (RAW_HALVES == 2 && !EARLY && ks == 1 && !(CCVPE_X4_SWITCH & 4)) {
+                            CCVPE_X4_STORE_RAW(0);
+                            CCVPE_X4_LOAD_RAW(c0n, 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
             };
@@ -312,11 +336,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (q & 1) mfma_phase(std::integral_constant<int, 1>{}, std::integral_constant<int, (S1 > 0 ? S1 : 1)>{});
                 else mfma_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, (S1 > 0 ? S1 : 1)>{});
             }
-            if (EARLY) { CCVPE_X4_STORE_RAW(0); }
-            CCVPE_X4_STORE_RAW(RAW_HALVES - 1);
+            if (!(CCVPE_X4_SWITCH & (4 | 64))) {
+                if (EARLY) { CCVPE_X4_STORE_RAW(0); }
+                CCVPE_X4_STORE_RAW(RAW_HALVES - 1);
+            } else if (CCVPE_X4_SWITCH & 64) {
+                float keep_ = 0.f;
+#pragma unroll
+                for (int i = 0; i < (EARLY ? 6 : 3); ++i) keep_ += raw[i].x + raw[i].y + raw[i].z + raw[i].w;
+                if (keep_ == 12345.f) Rs[tid] = keep_;
+            }
             __syncthreads();   // V image free again; next raw patch complete
         }
 
+        if (CCVPE_X4_SWITCH & 1) {   // timing only: one store per lane keeps the accumulators alive
+            float sum_ = 0.f;
+#pragma unroll
+            for (int x = 0; x < 9 * S0; ++x) sum_ += acc[x][0] + acc[x][1] + acc[x][2] + acc[x][3];
+            if (sum_ == 12345.f) p.dst[0].ptr[tid] = sum_;
+        } else
         // ---- epilogue: accumulators -> LDS (one round = RS slices), thread = (slice of the round, tile, channel) gathers its 36 xi,
         //      applies A^T M A, bias, activation, and stores its channel of the tile's 4 x 4 output pixels ----
         {
