@@ -56,7 +56,7 @@ int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
     h->vs = make_variant(cfg->variant);
     if (const char* e = getenv("CCVPE_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
     // the candidate-filter switches are diagnostics: with one of them set every plan is measured under it, table or not
-    for (const char* sw : {"CCVPE_TUNE_PREFER_PW", "CCVPE_TUNE_SPLITK", "CCVPE_TUNE_NO_BF16X3", "CCVPE_TUNE_BF16_ONLY", "CCVPE_NO_PW", "CCVPE_TUNE_IGNORE_TABLE"})
+    for (const char* sw : {"CCVPE_TUNE_PREFER_PW", "CCVPE_TUNE_PREFER_PROJ", "CCVPE_TUNE_SPLITK", "CCVPE_TUNE_NO_BF16X3", "CCVPE_TUNE_BF16_ONLY", "CCVPE_NO_PW", "CCVPE_TUNE_IGNORE_TABLE"})
         if (getenv(sw)) h->tuning_lookup = false;
     if (const char* e = getenv("CCVPE_GRAPH")) h->graph_mode = std::atoi(e) != 0;
     if (const char* e = getenv("CCVPE_FUSE_L1")) h->fuse_level1 = std::atoi(e) != 0;

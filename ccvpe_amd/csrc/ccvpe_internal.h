@@ -118,6 +118,8 @@ struct PackedConv {
     float* wino4x = nullptr;      // xi-split F(4x4,3x3) weights (kernels_wino4x.hip): layers of 24 .. 128 output channels
     size_t wino4x_bytes = 0;
     int wino4x_cfg = -1;
+    float* proj = nullptr;        // fragment-order copy of a gated deep-K 1x1 layer for kernels_proj.hip
+    size_t proj_bytes = 0;
 };
 struct BlockW {
     PackedConv expand, project;
@@ -186,6 +188,7 @@ struct Op {
     bool wino4_ok = false;        // ... with the F(4x4,3x3) weights packed as well
     bool wino4x_ok = false;       // ... with the xi-split F(4x4,3x3) weights packed
     bool is_pw = false;           // 1x1 conv / k2s2 transposed conv: the pointwise persistent tiles may serve it
+    bool proj_ok = false;         // gated project conv with the fragment-order weights packed (kernels_proj.hip)
     // two-stream execution (Plan::schedule): stream the op is issued on, ops of the other stream it must wait for,
     // and whether an op of the other stream waits for this one (then an event is recorded after it)
     int stream = 0;

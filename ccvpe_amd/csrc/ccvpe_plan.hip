@@ -29,6 +29,7 @@ ConvParams conv_params(const PackedConv& pc, const float* in, int in_ld, int B, 
     p.wino_w = pc.wino; p.wino_n16 = pc.wino_n16; p.wino_bytes = (unsigned)pc.wino_bytes;
     p.wino4_w = pc.wino4; p.wino4_bytes = (unsigned)pc.wino4_bytes;
     p.wino4x_w = pc.wino4x; p.wino4x_bytes = (unsigned)pc.wino4x_bytes; p.wino4x_cfg = pc.wino4x_cfg;
+    p.proj_w = pc.proj; p.proj_bytes = (unsigned)pc.proj_bytes;
     return p;
 }
 
@@ -132,6 +133,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
                 c.launch_conv(p, tile);
             }, 2.0 * B * oh * ow * mid * b.cout, 4.0 * B * oh * ow * (mid + b.cout * (1 + td.n)));
             pl.ops.back().is_pw = true;
+            pl.ops.back().proj_ok = pc->proj != nullptr && h->cfg.reserved[0] == 0;
         }
         out.tap[i] = o;
         pl.taps[tag + "_block" + std::to_string(i)] = {o, 0, o.C};

@@ -15,6 +15,7 @@ std::string tuning_key(ccvpe_handle_s* h, const Plan& pl, const Op& op) {
                   h->cfg.reserved[0], pl.B, op.name.c_str(), op.gemm_m, op.gemm_n, op.gemm_kpad, op.wino_ok ? 1 : 0, op.wino4_ok ? 1 : 0,
                   op.is_pw ? 1 : 0, op.bf16x3_only ? 1 : 0);
     if (op.wino4x_ok) std::strcat(buf, "x");
+    if (op.proj_ok) std::strcat(buf, "p");
     return buf;
 }
 
@@ -121,7 +122,13 @@ int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
             else if (conv_igemm_tile_is_wino4(t) && !op.wino4_ok) continue;
             static const bool prefer_pw = getenv("CCVPE_TUNE_PREFER_PW") != nullptr;   // test hook: pointwise tiles wherever they apply
             if (prefer_pw && op.is_pw && !op.bf16x3_only && !conv_igemm_tile_is_pw(t) && op.gemm_kpad <= 512) continue;
-            if (conv_igemm_tile_is_pw(t)) {
+            static const bool prefer_proj = getenv("CCVPE_TUNE_PREFER_PROJ") != nullptr;   // test hook: the deep-K project GEMM wherever it applies
+            if (prefer_proj && op.proj_ok && !conv_igemm_tile_is_proj(t)) continue;
+            if (conv_igemm_tile_is_proj(t)) {
+                ConvParams qq{}; qq.M = 1 << 20; qq.N = 16;
+                const int rt = (int)((long long)qq.M / conv_igemm_tile_blocks(qq, t)) / 16;   // the tile's row tiles
+                if (!op.proj_ok || !conv_proj_has(rt, op.gemm_n) || getenv("CCVPE_NO_PW")) continue;
+            } else if (conv_igemm_tile_is_pw(t)) {
                 ConvParams qq{}; qq.M = 16; qq.N = 1 << 20;
                 const int bn = (int)(((long long)qq.N) / conv_igemm_tile_blocks(qq, t));   // the tile's column width
                 if (!op.is_pw || op.bf16x3_only || !conv_pw_fits(bn, op.gemm_kpad) || getenv("CCVPE_NO_PW")) continue;

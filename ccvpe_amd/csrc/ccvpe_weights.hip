@@ -82,6 +82,12 @@ int pack_conv(ccvpe_handle_s* h, PackedConv& pc, int N, int taps, int cin, int c
     pc.N = N; pc.Kpad = kpad; pc.nchunks = K / 8; pc.cinp = cinp; pc.KH = KH; pc.KW = KW;
     int rc = upload(h, w, &pc.w);
     if (rc) return rc;
+    if (KH == 1 && KW == 1 && taps == 1 && cin == cinp && conv_proj_wanted(N, cin) && !getenv("CCVPE_NO_PROJ")) {
+        std::vector<float> up;
+        conv_proj_pack(N, cin, [&](int n, int c) { return get(n, 0, c); }, up);
+        pc.proj_bytes = up.size() * sizeof(float);
+        if ((rc = upload(h, up, &pc.proj))) return rc;
+    }
     if (KH == 3 && KW == 3 && cin == cinp && cin % 8 == 0 && (size_t)(cin / 8) * 16 * ((N + 15) / 16) * 512 < (1u << 31)) {
         std::vector<float> u;
         conv_wino_pack(N, cin, get, u, &pc.wino_n16);

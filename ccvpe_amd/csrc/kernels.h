@@ -92,6 +92,9 @@ struct ConvParams {
     const float* wino4x_w;     // [k-step][wave][16-byte load][64 lanes][4]
     unsigned wino4x_bytes;
     int wino4x_cfg;            // configuration index the weights were packed for (conv_wino4x_config(N))
+    // deep-K / narrow-N project GEMM (kernels_proj.hip): the 1x1 weights in MFMA fragment order, null = not packed
+    const float* proj_w;       // [Cin / 16 steps][ceil(N / 16) column tiles][64 lanes][4]
+    unsigned proj_bytes;
     // split F(4x4) form (kernels_wino4p.hip): per-stream scratch for the pre-transformed input V = B^T d B (null = unavailable)
     float* wino4_v;
     size_t wino4_v_floats;
@@ -136,12 +139,20 @@ size_t conv_wino4_pack(int N, int cin, const std::function<float(int, int, int)>
 bool conv_igemm_tile_is_wino(int tile);
 size_t conv_wino_pack(int N, int cin, const std::function<float(int, int, int)>& get, std::vector<float>& out, int* n16_out);
 // pointwise persistent kernel (kernels_pw.hip): 1x1 convs / k2s2 transposed convs with K <= 512
-struct PwTile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); };
+struct PwTile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); int proj_rt; };   // proj_rt > 0: a kernels_proj.hip tile of that many row tiles
 int pw_num_tiles();
 const PwTile* pw_tile(int i);
 bool conv_pw_supported(const ConvParams& p);
 bool conv_pw_fits(int bn, int kpad);
+bool conv_pw_tile_ok(int i, const ConvParams& p);   // tile i of the family can run this launch
+// deep-K project GEMM (kernels_proj.hip)
+bool conv_proj_supported(const ConvParams& p, int rt);
+void launch_proj(const ConvParams& p, int rt, hipStream_t s);
+bool conv_proj_wanted(int N, int cin);
+bool conv_proj_has(int rt, int N);
+size_t conv_proj_pack(int N, int cin, const std::function<float(int, int)>& get, std::vector<float>& out);
 bool conv_igemm_tile_is_pw(int tile);
+bool conv_igemm_tile_is_proj(int tile);   // a kernels_proj.hip tile (member of the pointwise family)
 int conv_igemm_last_tile();  // tile id of the most recent launch on this thread (then reset to 0)
 const char* conv_igemm_tile_name(int tile);
 

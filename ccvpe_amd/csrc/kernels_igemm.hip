@@ -344,6 +344,7 @@ int conv_igemm_num_tiles() { return NTILES + bf16x3_num_tiles() + wino_num_tiles
 bool conv_igemm_tile_is_wino(int tile) { tile &= 0xff; return tile > NTILES + bf16x3_num_tiles() && tile <= NTILES + bf16x3_num_tiles() + wino_num_tiles(); }
 static int pw_index(int tile) { return (tile & 0xff) - NTILES - bf16x3_num_tiles() - wino_num_tiles() - 1; }
 bool conv_igemm_tile_is_pw(int tile) { const int i = pw_index(tile); return i >= 0 && i < pw_num_tiles(); }
+bool conv_igemm_tile_is_proj(int tile) { return conv_igemm_tile_is_pw(tile) && pw_tile(pw_index(tile))->proj_rt > 0; }
 bool conv_igemm_tile_is_wino4(int tile) { return conv_igemm_tile_is_wino(tile) && wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->f == 4; }
 bool conv_igemm_tile_is_wino4p(int tile) { return conv_igemm_tile_is_wino4(tile) && wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->pre; }
 static int wino4x_cfg_of(int tile) { return conv_igemm_tile_is_wino(tile) ? wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->xcfg : -1; }
@@ -480,7 +481,7 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
     tile &= 0xff;
     if (conv_igemm_tile_is_bf16x3(tile) && (p.w_hi == nullptr || p.w_lo == nullptr)) tile = 0;   // planes not packed: fp32 path
     if (conv_igemm_tile_is_wino(tile) && !conv_wino_tile_supported(p, tile)) tile = 0;
-    if (conv_igemm_tile_is_pw(tile) && !(conv_pw_supported(p) && conv_pw_fits(pw_tile(pw_index(tile))->bn, p.Kpad))) tile = 0;   // not a shallow 1x1 layer
+    if (conv_igemm_tile_is_pw(tile) && !conv_pw_tile_ok(pw_index(tile), p)) tile = 0;   // not a layer this pointwise tile takes
     if (conv_igemm_tile_is_pw(tile)) splitk = 1;   // not a Winograd-shaped layer: implicit GEMM
     if (tile < 1 || tile > conv_igemm_num_tiles()) tile = pick_tile(p);
     if (p.in_split) {   // pre-split bf16 input: only the bf16x3 kernels can read it

@@ -169,17 +169,28 @@ static void launch_pw(const ConvParams& p, hipStream_t s) {
 }
 
 // bm = 16: rows are padded to one MFMA tile only; bn = 16 TN
+template <int RT>
+static void launch_proj_rt(const ConvParams& p, hipStream_t s) { launch_proj(p, RT, s); }
 static const PwTile PW_TILES[] = {
-    {16, 16, "conv_pw_16", launch_pw<1>},
-    {16, 32, "conv_pw_32", launch_pw<2>},
-    {16, 48, "conv_pw_48", launch_pw<3>},
-    {16, 80, "conv_pw_80", launch_pw<5>},
-    {16, 128, "conv_pw_128", launch_pw<8>},
-    {16, 64, "conv_pw_64", launch_pw<4>},
-    {16, 160, "conv_pw_160", launch_pw<10>},
+    {16, 16, "conv_pw_16", launch_pw<1>, 0},
+    {16, 32, "conv_pw_32", launch_pw<2>, 0},
+    {16, 48, "conv_pw_48", launch_pw<3>, 0},
+    {16, 80, "conv_pw_80", launch_pw<5>, 0},
+    {16, 128, "conv_pw_128", launch_pw<8>, 0},
+    {16, 64, "conv_pw_64", launch_pw<4>, 0},
+    {16, 160, "conv_pw_160", launch_pw<10>, 0},
+    // kernels_proj.hip: RT x 16 rows x ALL columns per workgroup, K split over its four waves (gated project convs with a deep K)
+    {16, 16, "conv_proj_r1", launch_proj_rt<1>, 1},
+    {32, 16, "conv_proj_r2", launch_proj_rt<2>, 2},
+    {64, 16, "conv_proj_r4", launch_proj_rt<4>, 4},
 };
 int pw_num_tiles() { return (int)(sizeof(PW_TILES) / sizeof(PW_TILES[0])); }
 const PwTile* pw_tile(int i) { return &PW_TILES[i]; }
+bool conv_pw_tile_ok(int i, const ConvParams& p) {
+    if (i < 0 || i >= pw_num_tiles()) return false;
+    if (PW_TILES[i].proj_rt > 0) return conv_proj_supported(p, PW_TILES[i].proj_rt);
+    return conv_pw_supported(p) && conv_pw_fits(PW_TILES[i].bn, p.Kpad);
+}
 // the weight slab [bn][Kpad + 4] and the four C patches must fit the LDS of a CU
 bool conv_pw_fits(int bn, int kpad) { return kpad <= PW_KMAX && ((size_t)bn * (kpad + 4) + 4 * 16 * (bn + 4)) * sizeof(float) <= 150 * 1024; }
 

@@ -254,6 +254,36 @@ def test_pointwise_persistent_tiles_everywhere_match_golden(name, monkeypatch):
     assert worst <= CONTRACT_RTOL
 
 
+@pytest.mark.parametrize("name,batch", [("vigor_prior180_circ", 1), ("kitti", 1), ("oxford", 3)])
+def test_deep_k_project_gemm_everywhere_matches_golden(name, batch, monkeypatch):
+    """CCVPE_TUNE_PREFER_PROJ routes every gated project conv whose width conv_proj_kernel takes (80 / 112 / 192 / 320 columns, K = 240
+    .. 1152 split over a workgroup's four waves, residual and concat-tap epilogues) through it, whatever the autotuner would pick:
+    goldens for the 9 outputs plus the aerial encoder taps; Oxford's 10 x 15 / 5 x 8 maps give ragged row tiles that span samples."""
+    monkeypatch.setenv("CCVPE_TUNE_PREFER_PROJ", "1")
+    cfg = gu.CONFIGS[name]
+    fx = gu.load(name)
+    m = build_model(cfg)
+    if batch == cfg["batch"]:
+        m.set_debug(True)
+        g, s = inputs(cfg)
+        worst = check_against_fixture(fx, m(g, s), RTOL)
+        assert worst <= CONTRACT_RTOL
+        if name == "vigor_prior180_circ":
+            for tap in ["sat_block4", "sat_block10", "sat_block15"]:
+                gu.compare("tap_" + tap, fx, m.read_tap(tap).numpy(), RTOL)
+    else:   # a batch the goldens do not hold: against the default plan of the same model
+        g, s = inputs(cfg, batch=batch)
+        out = [t.clone() for t in m(g, s)]
+        monkeypatch.delenv("CCVPE_TUNE_PREFER_PROJ")
+        ref = build_model(cfg)(g, s)
+        mag = raw_ori_magnitude(cfg, g, s)
+        for i, (a, b) in enumerate(zip(ref, out)):
+            if i == 2:
+                assert ori_weighted_error(a, b, mag) <= 1e-4
+            else:
+                assert (a - b).abs().max().item() <= 1e-4 * max(a.abs().max().item(), 1e-30), gu.OUTPUT_NAMES[i]
+
+
 @pytest.mark.parametrize("name", ["vigor_prior180_circ", "kitti", "oxford"])
 def test_image_resident_front_kernel_agrees_with_separate_launches(name, monkeypatch):
     """mbconv_image_kernel (blocks 2-15: expand + depthwise + pooling with the expanded image / strip in LDS) against the same
