@@ -251,7 +251,16 @@ def main() -> int:
         return step
 
     step = make_step(model, grd, sat, cache)
-    for _ in range(args.warmup):
+    # first call of the headline plan: weight ingestion + plan build (+ measuring whatever launches the tuning table does not know)
+    torch.cuda.synchronize(dev)
+    t_first = time.perf_counter()
+    if args.warmup > 0:
+        step()
+        torch.cuda.synchronize(dev)
+    t_first = time.perf_counter() - t_first
+    from ccvpe_amd import _lib as _cl
+    tuned_plans = _cl.load().ccvpe_tuning_generation(model._handle) if model._handle is not None else -1
+    for _ in range(max(args.warmup - 1, 0)):
         step()
     D.barrier()
     torch.cuda.synchronize(dev)
@@ -284,6 +293,9 @@ def main() -> int:
                    "parallelism": f"image-parallel x{world}, all_gather of 20 B/query results",
                    "schedule": "two streams per GPU (aerial encoder + orientation decoder on the second)" if two_streams else "single stream"},
     }
+
+    line["startup"] = {"first_step_s": t_first, "plans_measured_at_startup": tuned_plans,
+                       "note": "first call of the batch-32 plan: state_dict ingestion + weight packing + plan build; 0 plans measured = every launch came from the tuning table"}
 
     def latency_run(m, gg, ss, n=200, warm=12):
         """Per-call latency (synchronised after every step) and back-to-back throughput of one model / input."""
@@ -376,7 +388,7 @@ def main() -> int:
             gr[0] += ms; gr[1] += fl; gr[2] += by; gr[3] += 1; gr[4] += iss
         total_ms = sum(v[0] for v in groups.values())
         # tiled GEMM / Winograd launches (tag = tile name) - the candidates for the dominant kernel ...
-        mfma = {k: v for k, v in groups.items() if k.startswith(("conv_igemm", "conv_bf16x3", "conv_wino", "conv_pw"))}
+        mfma = {k: v for k, v in groups.items() if k.startswith(("conv_igemm", "conv_bf16x3", "conv_wino", "conv_pw", "conv_proj"))}
         dom = max(mfma, key=lambda k: mfma[k][0])
         ms, fl, by, cnt, iss = mfma[dom]
         # ... and every launch whose arithmetic runs on the matrix cores: + the fused last decoder level (level1_kernel), the fused
