@@ -233,8 +233,19 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
             c.grd = c.ptr(pl->io_grd); c.sat = c.ptr(pl->io_sat);
             c.out.logits_flattened = c.ptr(pl->io_logits); c.out.heatmap = c.ptr(pl->io_heat); c.out.ori = c.ptr(pl->io_ori);
             for (int k = 0; k < 6; ++k) c.out.matching_score[k] = c.ptr(pl->io_ms[k]);
-            HIPCHK(hipMemcpyAsync((void*)c.grd, ugrd, (size_t)mb * 3 * gh * gw * sizeof(float), hipMemcpyDeviceToDevice, stream));
-            HIPCHK(hipMemcpyAsync((void*)c.sat, usat, (size_t)mb * 3 * CCVPE_SAT_HW * CCVPE_SAT_HW * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            {   // both inputs in one launch (sizes are multiples of 4 floats: 3 x H x W with even H or W - else the runtime copies)
+                const size_t ng = (size_t)mb * 3 * gh * gw, ns = (size_t)mb * 3 * CCVPE_SAT_HW * CCVPE_SAT_HW;
+                if (ng % 4 == 0 && ((uintptr_t)ugrd % 16) == 0 && ((uintptr_t)usat % 16) == 0) {
+                    MultiCopy mc{};
+                    mc.src[0] = ugrd; mc.dst[0] = (float*)c.grd; mc.n[0] = ng;
+                    mc.src[1] = usat; mc.dst[1] = (float*)c.sat; mc.n[1] = ns;
+                    mc.count = 2;
+                    launch_multi_copy(mc, stream);
+                } else {
+                    HIPCHK(hipMemcpyAsync((void*)c.grd, ugrd, ng * sizeof(float), hipMemcpyDeviceToDevice, stream));
+                    HIPCHK(hipMemcpyAsync((void*)c.sat, usat, ns * sizeof(float), hipMemcpyDeviceToDevice, stream));
+                }
+            }
             if (!pl->exec && pl->runs >= 1) {   // first call ran eagerly (lazy kernel attributes are set): capture now
                 // capture on a private stream (the caller's may be the legacy null stream, which cannot capture)
                 hipGraph_t graph = nullptr;
@@ -253,12 +264,18 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
             if (pl->exec) HIPCHK(hipGraphLaunch(pl->exec, stream));
             else if (int rrc = run_ops(h, *pl, c, stream)) return rrc;
             pl->runs++;
-            HIPCHK(hipMemcpyAsync(user.logits_flattened, c.out.logits_flattened, (size_t)mb * npx * sizeof(float), hipMemcpyDeviceToDevice, stream));
-            HIPCHK(hipMemcpyAsync(user.heatmap, c.out.heatmap, (size_t)mb * npx * sizeof(float), hipMemcpyDeviceToDevice, stream));
-            HIPCHK(hipMemcpyAsync(user.ori, c.out.ori, (size_t)mb * 2 * npx * sizeof(float), hipMemcpyDeviceToDevice, stream));
-            for (int k = 0; k < 6; ++k) {
-                const size_t hw = (size_t)(8 << k) * (8 << k);
-                HIPCHK(hipMemcpyAsync(user.matching_score[k], c.out.matching_score[k], (size_t)mb * h->rolls[k] * hw * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            {   // the nine outputs in one launch
+                MultiCopy mc{};
+                auto add = [&](float* dst, const float* src, size_t n) { mc.src[mc.count] = src; mc.dst[mc.count] = dst; mc.n[mc.count] = n; ++mc.count; };
+                add(user.logits_flattened, c.out.logits_flattened, (size_t)mb * npx);
+                add(user.heatmap, c.out.heatmap, (size_t)mb * npx);
+                add(user.ori, c.out.ori, (size_t)mb * 2 * npx);
+                bool aligned = true;
+                for (int k = 0; k < 6; ++k) add(user.matching_score[k], c.out.matching_score[k], (size_t)mb * h->rolls[k] * ((size_t)(8 << k) * (8 << k)));
+                for (int i = 0; i < mc.count; ++i) aligned = aligned && mc.n[i] % 4 == 0 && ((uintptr_t)mc.dst[i] % 16) == 0 && ((uintptr_t)mc.src[i] % 16) == 0;
+                if (aligned) launch_multi_copy(mc, stream);
+                else
+                    for (int i = 0; i < mc.count; ++i) HIPCHK(hipMemcpyAsync(mc.dst[i], mc.src[i], mc.n[i] * sizeof(float), hipMemcpyDeviceToDevice, stream));
             }
         } else if (!profile) {
             if (int rrc = run_ops(h, *pl, c, stream)) return rrc;

@@ -329,6 +329,10 @@ struct MetricsOut { double pixel_distance, meter_distance, prob_at_gt, angle_pre
 void launch_metrics(const PoseOut* pose, const float* heat, int B, int W, int n, const int* gt_index, const float* gt_cos_sin,
                     const double* meter_per_pixel, const double* heading_deg, MetricsOut* out, hipStream_t s);
 
+// several device-to-device copies in ONE launch (float counts, all pointers 16-byte aligned, counts multiples of 4): the staging
+// copies around a hipGraph replay - 11 runtime copy launches of ~5 us each per batch-1 frame otherwise
+struct MultiCopy { const float* src[12]; float* dst[12]; unsigned long long n[12]; int count; };
+void launch_multi_copy(const MultiCopy& mc, hipStream_t s);
 void launch_fill_random(float* p, size_t n, uint32_t seed, hipStream_t s);   // ~N(0,1) floats (autotune operands)
 void launch_nhwc_to_nchw(const float* in, int in_ld, int coff, int C, int B, int HW, float* out, hipStream_t s);
 

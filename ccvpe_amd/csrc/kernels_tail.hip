@@ -10,6 +10,8 @@
 
 namespace ccvpe {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 // thread = one output pixel; 9 taps x 16 channels = 4 float4 per tap, NHWC input (64 B per pixel).
 template <int COUT>
 __global__ __launch_bounds__(256) void tail_conv_kernel(const TailConvParams p) {
@@ -343,6 +345,22 @@ __global__ __launch_bounds__(256) void fill_random_kernel(float* __restrict__ p,
         p[i] = acc;
     }
 }
+__global__ __launch_bounds__(256) void multi_copy_kernel(const MultiCopy mc) {
+    // blockIdx.y = segment; 16-byte pieces, grid-stride
+    const int seg = blockIdx.y;
+    const unsigned long long n4 = mc.n[seg] >> 2;
+    const f32x4_t* __restrict__ src = reinterpret_cast<const f32x4_t*>(mc.src[seg]);
+    f32x4_t* __restrict__ dst = reinterpret_cast<f32x4_t*>(mc.dst[seg]);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256) dst[i] = src[i];
+}
+void launch_multi_copy(const MultiCopy& mc, hipStream_t s) {
+    if (mc.count <= 0) return;
+    unsigned long long mx = 0;
+    for (int i = 0; i < mc.count; ++i) mx = std::max(mx, mc.n[i]);
+    const int gx = (int)std::min<unsigned long long>((mx / 4 + 255) / 256, 512);
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(std::max(gx, 1), mc.count), dim3(256), 0, s, mc);
+}
+
 void launch_fill_random(float* p, size_t n, uint32_t seed, hipStream_t s) {
     if (n == 0) return;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 32);
