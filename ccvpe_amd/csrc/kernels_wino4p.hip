@@ -26,7 +26,6 @@ static constexpr int W4P_PITCH = 20;                 // floats per raw row (18 u
 static constexpr int W4P_PLANE = 385;                // floats per raw channel plane
 static constexpr int W4P_GCH = 16;                   // input channels per group (4 k-steps)
 static constexpr int W4P_VFLOATS = 4 * 18 * 64 * 2;  // one V group: [k-step][xi pair][lane][2]
-static constexpr int W4P_RAW_F4 = 18 * 18 * 4;       // float4 items of one raw group
 
 __device__ __forceinline__ void w4p_bt(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
                                        float& t0, float& t1, float& t2, float& t3, float& t4, float& t5) {

@@ -1,3 +1,5 @@
+"""Dev tool (GPU box): 40 batch-1 frames (hipGraph replay) for `rocprofv3 --kernel-trace -- python3 tools/b1_frames.py`; summarise with
+tools/b1_trace_summary.py <trace dir>."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
