@@ -28,6 +28,10 @@ static constexpr int DSINK = DT + 2;  // sink rows behind the D tile: offset (dy
 static constexpr int AROWS = ((AT * AT + 15) / 16) * 16;   // A tile rows incl. the padding rows of the last m-tile
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef CCVPE_L1_TAIL_W_LDS
+#define CCVPE_L1_TAIL_W_LDS 1   // 0: the last conv's weights from global memory (rounds 1-2)
+#endif
+
 static constexpr int KCH_MAX = 4;     // input channels <= 64 (16 per k-chunk); the host falls back to the unfused path beyond
 static constexpr int XI_MAX = (XT * XT * KCH_MAX * 4 + 255) / 256;   // float4 items per thread of one X tile
 
@@ -64,6 +68,13 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
     // the two epilogues are tabulated (stage 1) or affine (stage 2); tiles whose halo lies fully inside the image
     // (88 % of them) also skip every bounds test.
     if (tid < 112) dtab[tid] = tid < XT * XT ? ((2 * (tid / XT)) * DT + 2 * (tid % XT)) * PS : DT * DT * PS;
+#if CCVPE_L1_TAIL_W_LDS
+    // weights of the last conv -> LDS once (round 3): read from global memory inside the persistent loop they are VECTOR loads (the kernel
+    // stores to global memory, so hipcc may not scalarise them) with an `s_waitcnt vmcnt(0)` behind every tap - nine exposed L2 round
+    // trips per tile.  From LDS every lane reads the same address (a broadcast, one bank access) under lgkmcnt.
+    float* wts = reinterpret_cast<float*>(dtab + 112);            // [9][COUT][16]
+    for (int i = tid; i < 9 * COUT * 16; i += 256) wts[i] = p.wt[i];
+#endif
     const int kch = CXP >> 4;
     // deconv weights: wave w owns output parity (dy,dx) = (w>>1, w&1); B operand of k-chunk kc, MFMA j is
     // Wd[n = w*16 + (lane&15)][16*kc + 4*(lane>>4) + j]
@@ -78,7 +89,9 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
     // channel-major accumulators (weights are the A operand of the MFMAs): a lane holds channels 4 (lane >> 4) .. + 3 of ONE pixel
     const f32x4 bd = *reinterpret_cast<const f32x4*>(p.bd + 4 * (lane >> 4));
     const f32x4 ba = *reinterpret_cast<const f32x4*>(p.ba + 4 * (lane >> 4));
-    const float* __restrict__ wt = p.wt;   // [9][COUT][16], uniform -> scalar loads; a channel pair is one aligned SGPR pair
+#if !CCVPE_L1_TAIL_W_LDS
+    const float* __restrict__ wt = p.wt;   // [9][COUT][16]
+#endif
 
     // X tile staging: float4 item i = tid + it*256 -> pixel i / c4n, channels 4*(i % c4n)
     const int c4n = CXP >> 2;
@@ -251,7 +264,11 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(ap + c4 * 4);
 #pragma unroll
                 for (int c = 0; c < COUT; ++c) {
+#if CCVPE_L1_TAIL_W_LDS
+                    const float* wp = wts + (t * COUT + c) * 16 + c4 * 4;
+#else
                     const float* wp = wt + (t * COUT + c) * 16 + c4 * 4;
+#endif
                     o2[c] = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{wp[0], wp[1]}, o2[c]);
                     o2[c] = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{wp[2], wp[3]}, o2[c]);
                 }
@@ -289,7 +306,7 @@ size_t level1_lds_bytes(int cxp, int cout) {
     const int XS = cxp + 4;
     const size_t r0f = std::max<size_t>((size_t)XT * XT * XS, (size_t)AROWS * PS);
     (void)cout;
-    return (r0f + (size_t)(DT * DT + DSINK) * PS + 112) * sizeof(float);
+    return (r0f + (size_t)(DT * DT + DSINK) * PS + 112 + 9 * 2 * 16) * sizeof(float);   // + the tail conv's weights (<= 2 output channels)
 }
 
 void launch_level1(const Level1Params& p, hipStream_t s) {
