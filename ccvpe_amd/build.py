@@ -91,7 +91,8 @@ def _build_locked(force: bool, verbose: bool) -> str:
     if failed:
         raise RuntimeError("hipcc compilation failed")
     tmp_lib = f"{LIB}.tmp.{os.getpid()}"
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib, *objs]
+    # --no-undefined: a kernel whose host stub went missing (hipcc's host pass can drop one silently) fails HERE, not at dlopen on the GPU box
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined", "-o", tmp_lib, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -9,23 +9,42 @@
 // way, two launches of 75 + 60 us).  The tile form of kernels_mbconv.hip does not pay here: an 8x8 tile of a 5x5 layer
 // recomputes 2.25x of the expand GEMM.  At these resolutions the WHOLE image of a 16-channel chunk fits in LDS
 // (36 x 36 pixels x 80 B = 104 KB), so nothing is recomputed and there is no halo logic on the input at all:
-//   * a 512-thread workgroup owns (sample, every CG-th chunk of 16 expanded channels);
-//   * expand: wave w takes m-tiles w, w + 8, ... of the [pixels x Cin] x [Cin x 16] GEMM, two at a time; the A operand
-//     (the block input, NHWC) goes from global memory / L2 straight into the MFMA registers, the B operand (16 rows of
-//     the expand weight) sits in registers for the chunk; bias + swish, then the accumulator rows are scattered into the
-//     zero-padded (or horizontally wrapped) E image through a pixel -> offset table;
+//   * a workgroup owns (sample, every CG-th chunk of 16 expanded channels);
+//   * expand: wave w takes m-tiles w, w + NWV, ... of the [pixels x Cin] x [Cin x 16] GEMM.  Both operands reach the MFMA
+//     registers THROUGH LDS (round 3): in the MFMA layout lane l holds row (l & 15), so four consecutive lanes of a direct
+//     16-byte load hit four different rows - the texture addresser then moves 18 B/clk per CU (tools/ubench_ta.hip; the loop
+//     spent 80 % of its time issuing loads, tools/time_ops.py + CCVPE_MI_CLOCK).  The same bytes with lane l -> row (l >> 2),
+//     piece (l & 3) move at 60 B/clk: every wave brings its m-tile in with LDS-DMA in that order (one instruction per 16 input
+//     channels, pieces rotated by (row >> 2) so the MFMA-layout read back is bank-conflict free), reads it into registers,
+//     requests the following tile into the same buffer and runs the MFMA chain; the chunk's expand weights take the same road
+//     once per workgroup instead of once per wave.  (Also built and measured: the tiles through registers - coalesced loads a step
+//     ahead into two register sets, 16-byte LDS writes in lane order and the same read back right before use; 10-14 KB per wave in
+//     flight instead of the buffer's 4-12 KB, yet 1.4 % slower over the 29 launches: 2.415 against 2.381 ms at batch 32.)
+//   * bias + swish, then the accumulator rows are scattered into the zero-padded (or horizontally wrapped) E image through a
+//     pixel -> offset table;
 //   * depthwise: thread = (4 channels, TX x TY output patch); the K x K taps come from LDS once per chunk, every input
 //     row of the patch window is read once and used by all taps; bias + swish, 16-byte stores, channel sums for the
 //     squeeze-excite pool reduced in a fixed order (wave shuffles, then 8 partials through LDS) -> deterministic;
-//   * two barriers per chunk; the next chunk's expand weights are requested before the depthwise phase starts.
+//   * two barriers per chunk; the next chunk's expand weights and first m-tiles land under the depthwise phase.
 // Samples are pinned to XCDs (sample b only on workgroups with id % 8 == b % 8) so the ~40-70 passes over a sample's
 // input hit that XCD's L2.
 #include "igemm_common.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace ccvpe {
+
+#ifndef CCVPE_MI_CLOCK
+#define CCVPE_MI_CLOCK 0   // dev builds (tools/build_variant.sh): 1 = every wave sums s_memtime per phase (unit set-up, expand, barrier, depthwise, tail)
+#endif
+#if CCVPE_MI_CLOCK
+__device__ unsigned long long g_mi_clk[12];
+#define CCVPE_MI_STAMP(i_) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); clk[i_] += t_ - tprev; tprev = t_; }
+#else
+#define CCVPE_MI_STAMP(i_)
+#endif
 
 static constexpr int EPS = 20;        // floats per pixel of the E image (16 + 4 pad: the MFMA-layout scatter is conflict-free)
 
@@ -43,13 +62,16 @@ struct MbImgParams {
 };
 
 // NT = 512 threads (8 waves, one workgroup per CU) for the large images, 256 (two workgroups per CU, out of phase) when two
-// E images fit the LDS.  (Measured and dropped: keeping the input m-tiles of a <= 256-pixel image in registers across all
-// chunks - the expand and depthwise phases of a chunk simply add up, 55 + 40 us on block 12, and one workgroup per CU has
-// nothing to overlap them with.)
-template <int K, int S, int KCH, int TX, int TY, int NT>
+// workgroups' LDS fits.  SK = 16-channel groups per staging step: the whole m-tile (SK = KCH) where the LDS has room for
+// NT / 64 x KCH KB beside the E image, else half of it (two steps per tile).  (Measured and dropped: keeping the input m-tiles of a
+// <= 256-pixel image in registers across all chunks.)
+template <int K, int S, int KCH, int SK, int TX, int TY, int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mbconv_image_kernel(const MbImgParams q) {
     constexpr int NWV = NT / 64;
     constexpr int WW = (TX - 1) * S + K;
+    constexpr int NS = (KCH + SK - 1) / SK;              // staging steps per m-tile
+    static_assert(NS <= 2, "whole or half tiles");
+    typedef __attribute__((address_space(3))) void* lds_ptr;
     const MbFrontParams& p = q.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e_floats = (q.HPa * q.WPa + 1) * EPS;      // + one sink pixel
@@ -59,8 +81,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
     float* wks = reinterpret_cast<float*>(dtab + q.NMT * 16);   // [K*K][16] depthwise taps of the chunk
     float* bds = wks + K * K * 16;                         // [16] depthwise bias
     float* red = bds + 16;                                 // [NT/64][16] per-wave pooling sums
+    float* Wst = red + NWV * 16;                           // [KCH][256] expand weights of the chunk, staged image (below)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // (uniform for the compiler too: LDS-DMA bases and offsets are scalars)
+    float* stg = Wst + KCH * 256 + wave * (SK * 256);      // [SK][256] this wave's m-tile (or half of it)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Work = the flattened list of (unit, chunk) items, unit = (sample, strip), unit-major; a workgroup takes an equal
     // contiguous share, and the shares are dealt XCD-major (XCD x owns a contiguous eighth of the list): a sample's 40-70
     // passes over its input stay in ONE L2 (dealt round robin, every L2 saw every sample: block 9 0.091 -> 0.134 ms)
@@ -69,31 +94,44 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
     const int it_lo = (int)((long long)total * wgx / gridDim.x), it_hi = (int)((long long)total * (wgx + 1) / gridDim.x);
     if (it_lo >= it_hi) return;
     const int sink = q.HPa * q.WPa * EPS;
-    const unsigned a_lane = (unsigned)(((lane & 15) * p.Cin + 4 * (lane >> 4)) * 4);    // row (lane & 15) of an m-tile, channels 4 (lane >> 4)
-    const unsigned a_mt = (unsigned)(16 * p.Cin * 4);                                    // bytes per m-tile
+    // Staged image of a [16 rows x 16 channels] block (1 KB, one LDS-DMA instruction): DMA lane l = 4 r + t fetches row r, 16-byte
+    // piece (t - (r >> 2)) & 3 of the block - the four lanes of a row read one 64-byte run - and lands at byte 16 l; the MFMA lane
+    // (g = l >> 4, r = l & 15) finds its piece g at 64 r + 16 ((g + (r >> 2)) & 3): the 16 lanes of one read phase hit 16 different
+    // 16-byte bank groups.  The K order (channel 16 kc + 4 g + e at MFMA e of group kc) is the same on both operands.
+    const int dr = lane >> 2, dpc = ((lane & 3) - (dr >> 2)) & 3;
+    const unsigned a_dma = (unsigned)((dr * p.Cin + 4 * dpc) * 4), w_dma = (unsigned)((dr * p.cinp + 4 * dpc) * 4);
+    const unsigned a_mt = (unsigned)(16 * p.Cin * 4), w_ch = (unsigned)(16 * p.cinp * 4);      // bytes per m-tile / per chunk of weights
+    const int rd_off = 16 * (lane & 15) + 4 * (((lane >> 4) + ((lane & 15) >> 2)) & 3);         // floats
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.we), 0, (unsigned)((size_t)p.mid * p.cinp * 4), 0x00020000);
     const int dq4 = tid & 3, slot = tid >> 2;          // depthwise: channel quad, patch slot (NT / 4 slots)
     const int npatch = q.NPX * q.NPY;
 
-    f32x4 wf[KCH];                                      // B fragments: We[16 ch + (lane & 15)][16 kc + 4 (lane >> 4) + e]
-#define CCVPE_MI_LOAD_W(c_)                                                                                      \
-    _Pragma("unroll") for (int kc = 0; kc < KCH; ++kc)                                                           \
-        wf[kc] = *reinterpret_cast<const f32x4*>(p.we + (size_t)((c_) * 16 + (lane & 15)) * p.cinp + kc * 16 + 4 * (lane >> 4));
+    // expand weights of chunk c_ -> Wst: the workgroup's waves share the KCH instructions
+#define CCVPE_MI_DMA_W(c_)                                                                                       \
+    for (int kc = wave; kc < KCH; kc += NWV)                                                                     \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr)(Wst + kc * 256), 16, w_dma + (unsigned)(c_) * w_ch, kc * 64, 0, 0);
+    // staging step st_ of m-tile mt_ (rows past the unit's pixels and tiles past its last: the descriptor returns zeros)
+#define CCVPE_MI_DMA_A(rsrc_, nmt_, mt_, st_)                                                                    \
+    {                                                                                                            \
+        const unsigned vo_ = (mt_) < (nmt_) ? a_dma + (unsigned)(mt_) * a_mt : 0x80000000u;                     \
+        const __amdgpu_buffer_rsrc_t rs_ = rsrc_;   /* (a struct member as the argument: hipcc's host pass drops the kernel's stub without a word) */ \
+        _Pragma("unroll") for (int j = 0; j < SK; ++j)                                                           \
+            if ((st_) * SK + j < KCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_ptr)(stg + j * 256), 16, vo_, ((st_) * SK + j) * 64, 0, 0); \
+    }
     // depthwise taps / bias of a chunk: fetched into registers a phase ahead, parked in LDS after the chunk barrier
+    // (every thread loads - clamped addresses - and only the owners store: a load under a condition makes hipcc copy the loop-carried
+    // registers at the join and wait for the loads right there)
     const bool tap_thread = tid < K * K * 4, bias_thread = tid >= NT - 16;
-    f32x4 tapv = {0.f, 0.f, 0.f, 0.f};
-    float biasv = 0.f;
+    const int tap_row = min(tid >> 2, K * K - 1), bias_col = max(tid - (NT - 16), 0);
+    f32x4 tapv;
+    float biasv;
 #define CCVPE_MI_LOAD_TAPS(c_)                                                                                   \
     {                                                                                                            \
-        if (tap_thread) tapv = *reinterpret_cast<const f32x4*>(p.wd + (size_t)(tid >> 2) * p.mid + (c_) * 16 + (tid & 3) * 4); \
-        if (bias_thread) biasv = p.bd[(c_) * 16 + tid - (NT - 16)];                                               \
+        tapv = *reinterpret_cast<const f32x4*>(p.wd + (size_t)tap_row * p.mid + (c_) * 16 + (tid & 3) * 4);      \
+        biasv = p.bd[(c_) * 16 + bias_col];                                                                      \
     }
-    // A operand of one m-tile: KCH 16-byte pieces per lane; two register sets, the next m-tile always in flight
-    f32x4 abuf[2][KCH];
-#define CCVPE_MI_LOAD_A(set_, mt_)                                                                               \
-    _Pragma("unroll") for (int kc = 0; kc < KCH; ++kc)                                                           \
-        abuf[set_][kc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (mt_) < NMT ? a_lane + (unsigned)(mt_) * a_mt : 0x80000000u, kc * 64, 0));
-    // one m-tile: 4 KCH dependent MFMAs (the SIMD's other wave fills the dependent-issue gaps; the expand weights are the A
-    // operand, so a lane ends up with 4 consecutive channels of ONE pixel), bias + swish, one 16-byte scatter per lane
+    // bias + swish on the accumulator rows (the expand weights are the A operand, so a lane ends up with 4 consecutive channels of
+    // ONE pixel), one 16-byte scatter per lane
 #define CCVPE_MI_SCATTER(acc_, mt_)                                                                              \
     {                                                                                                            \
         const int pos = ptab[(mt_) * 16 + (lane & 15)];                                                          \
@@ -102,32 +140,49 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
         *reinterpret_cast<f32x4*>(Es + pos + 4 * (lane >> 4)) = v;                                               \
         if (p.circular) *reinterpret_cast<f32x4*>(Es + dtab[(mt_) * 16 + (lane & 15)] + 4 * (lane >> 4)) = v;   \
     }
-#define CCVPE_MI_MTILE(set_, mt_)                                                                                \
-    {                                                                                                            \
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};                                                                        \
-        _Pragma("unroll") for (int kc = 0; kc < KCH; ++kc)                                                       \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kc][e], abuf[set_][kc][e], acc, 0, 0, 0); \
-        CCVPE_MI_SCATTER(acc, mt_);                                                                              \
+#if CCVPE_MI_CLOCK
+#define CCVPE_MI_VMWAIT() { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); clkw += __builtin_amdgcn_s_memtime() - t0_; }
+#else
+#define CCVPE_MI_VMWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
+    // A unit = (sample, strip): output rows [oyA, oyB), input rows [yA, yB) (clamped to the image: rows outside stay zero in the E
+    // image); E row 0 is input row ey0 (negative in the first strip: the static top padding)
+    struct Unit { int b, oyA, oyB, ey0, yA, P, NMT; __amdgpu_buffer_rsrc_t rsrc; };
+    auto decode_unit = [&](int u) {
+        Unit r;
+        r.b = u / q.NST;
+        const int st = u - r.b * q.NST;
+        r.oyA = st * q.RO; r.oyB = min(r.oyA + q.RO, p.OH);
+        r.ey0 = r.oyA * S - q.PT;
+        r.yA = max(r.ey0, 0);
+        const int yB = min((r.oyB - 1) * S - q.PT + K, p.H);
+        r.P = (yB - r.yA) * p.W;
+        r.NMT = (r.P + 15) >> 4;                          // <= q.NMT
+        r.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + ((size_t)r.b * p.H + r.yA) * p.W * p.Cin), 0, (unsigned)((size_t)r.P * p.Cin * 4), 0x00020000);
+        return r;
+    };
+    // Everything an item needs from global memory is requested ONE item ahead, at fixed places and unconditionally (the last item
+    // requests itself again): its expand weights after the barrier that ends the previous expand phase, its taps / bias and every
+    // wave's first m-tile at the end of that phase.
+    int unit = -1;
+    Unit cur = decode_unit(it_lo / q.nchunks);
+    {
+        const int ch = it_lo - (it_lo / q.nchunks) * q.nchunks;
+        CCVPE_MI_DMA_W(ch);
+        CCVPE_MI_LOAD_TAPS(ch);
+        CCVPE_MI_DMA_A(cur.rsrc, cur.NMT, wave, 0);
     }
-
-    // state of the current unit (set at its first item)
-    int unit = -1, b = 0, oyA = 0, oyB = 0, NMT = 0;
-    __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0, 0x00020000);
-
+#if CCVPE_MI_CLOCK
+    unsigned long long clk[5] = {0, 0, 0, 0, 0}, clkw = 0, tprev = __builtin_amdgcn_s_memtime();
+#endif
     for (int it = it_lo; it < it_hi; ++it) {
         const int u = it / q.nchunks, ch = it - u * q.nchunks;
+        const int b = cur.b, oyA = cur.oyA, oyB = cur.oyB, NMT = cur.NMT;
+        const __amdgpu_buffer_rsrc_t x_rsrc = cur.rsrc;
         if (u != unit) {
-            // ---- new (sample, strip): output rows [oyA, oyB), input rows [yA, yB) (clamped to the image: rows outside stay
-            // zero in the E image); E row 0 is input row ey0 (negative in the first strip: the static top padding) ----
             unit = u;
-            b = u / q.NST;
-            const int st = u - b * q.NST;
-            oyA = st * q.RO; oyB = min(oyA + q.RO, p.OH);
-            const int ey0 = oyA * S - q.PT;
-            const int yA = max(ey0, 0), yB = min((oyB - 1) * S - q.PT + K, p.H);
-            const int P = (yB - yA) * p.W;
-            NMT = (P + 15) >> 4;                         // <= q.NMT
-            x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + ((size_t)b * p.H + yA) * p.W * p.Cin), 0, (unsigned)((size_t)P * p.Cin * 4), 0x00020000);
+            const int P = cur.P, yA = cur.yA, ey0 = cur.ey0;
             // (the barrier that ended the previous item already guarantees nobody still reads the E image or the tables)
             for (int i = tid * 4; i < e_floats; i += NT * 4) *reinterpret_cast<f32x4*>(Es + i) = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int i = tid; i < q.NMT * 16; i += NT) {
@@ -144,33 +199,56 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
                 }
                 ptab[i] = po; dtab[i] = dq;
             }
-            CCVPE_MI_LOAD_W(ch);
-            CCVPE_MI_LOAD_TAPS(ch);
-            CCVPE_MI_LOAD_A(0, wave);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (first item: the weights of its chunk have landed before anyone reads Wst)
             __syncthreads();
         }
+        CCVPE_MI_STAMP(0);
         const int ch0 = ch * 16;
+        // the item after this one (itself again behind the last): its unit's pixels, for the tile requests below
+        const int itn = min(it + 1, it_hi - 1);
+        const int un = itn / q.nchunks, chn = itn - un * q.nchunks;
+        if (un != unit) cur = decode_unit(un);             // (scalar state only; this item keeps the copies made above)
         // depthwise taps and bias of this chunk -> LDS (read after the barrier below)
         if (tap_thread) *reinterpret_cast<f32x4*>(wks + (tid >> 2) * 16 + (tid & 3) * 4) = tapv;
         if (bias_thread) bds[tid - (NT - 16)] = biasv;
         const f32x4 be = *reinterpret_cast<const f32x4*>(p.be + ch0 + 4 * (lane >> 4));   // channel-major accumulators: 4 channels of one pixel per lane
+        f32x4 wf[KCH];                                      // A fragments: We[16 ch + (lane & 15)][16 kc + 4 (lane >> 4) + e]
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) wf[kc] = *reinterpret_cast<const f32x4*>(Wst + kc * 256 + rd_off);
 
-        // ---- expand: m-tiles wave, wave + NWV, ...; set 0 holds the first one already ----
-        for (int mt = wave; mt < NMT;) {
-            CCVPE_MI_LOAD_A(1, mt + NWV);
-            CCVPE_MI_MTILE(0, mt);
-            mt += NWV;
-            if (mt >= NMT) break;
-            CCVPE_MI_LOAD_A(0, mt + NWV);
-            CCVPE_MI_MTILE(1, mt);
-            mt += NWV;
+        // ---- expand: m-tiles wave, wave + NWV, ...; the first one was requested an item ago ----
+        for (int mt = wave; mt < NMT; mt += NWV) {
+            // the tile this wave stages next: its following tile of this item, else its first tile of the next item
+            const bool last = mt + NWV >= NMT;
+            const __amdgpu_buffer_rsrc_t n_rsrc = last ? cur.rsrc : x_rsrc;
+            const int n_nmt = last ? cur.NMT : NMT, n_mt = last ? wave : mt + NWV;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                CCVPE_MI_VMWAIT();                          // this step's DMA has landed
+                f32x4 r[SK];
+#pragma unroll
+                for (int j = 0; j < SK; ++j) if (st * SK + j < KCH) r[j] = *reinterpret_cast<const f32x4*>(stg + j * 256 + rd_off);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and is in registers before the next request may overwrite it
+                __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise spreads the reads over the MFMA chain and the request goes out behind it)
+                if (st + 1 < NS) { CCVPE_MI_DMA_A(x_rsrc, NMT, mt, st + 1); }
+                else { CCVPE_MI_DMA_A(n_rsrc, n_nmt, n_mt, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < SK; ++j)
+                    if (st * SK + j < KCH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[st * SK + j][e], r[j][e], acc, 0, 0, 0);
+                    }
+            }
+            CCVPE_MI_SCATTER(acc, mt);
         }
-        // the next item's weights, taps and (same unit) first m-tile land under the depthwise phase
-        if (it + 1 < it_hi) {
-            const int un = (it + 1) / q.nchunks, chn = it + 1 - un * q.nchunks;
-            if (un == unit) { CCVPE_MI_LOAD_W(chn); CCVPE_MI_LOAD_TAPS(chn); CCVPE_MI_LOAD_A(0, wave); }
-        }
-        __syncthreads();                                   // E image, taps and bias of this chunk complete
+        if (wave >= NMT) { CCVPE_MI_DMA_A(cur.rsrc, cur.NMT, wave, 0); }   // (a wave without tiles here may have one in the next unit)
+        CCVPE_MI_LOAD_TAPS(chn);
+        CCVPE_MI_STAMP(1);
+        __syncthreads();                                   // E image, taps and bias of this chunk complete; everybody holds the weights
+        CCVPE_MI_STAMP(2);
+        CCVPE_MI_DMA_W(chn);                               // lands under the depthwise phase
 
         // ---- depthwise K x K, stride S, from the E image ----
         const f32x4 bd = *reinterpret_cast<const f32x4*>(bds + dq4 * 4);
@@ -217,13 +295,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
                     }
                 }
         }
+        CCVPE_MI_STAMP(3);
         // channel sums: lanes with equal quad inside the wave (xor over lane bits 2..5), then the waves through LDS
 #pragma unroll
         for (int off = 4; off < 64; off <<= 1)
 #pragma unroll
             for (int e = 0; e < 4; ++e) pool[e] += __shfl_xor(pool[e], off);
         if (lane < 4) *reinterpret_cast<f32x4*>(red + wave * 16 + lane * 4) = pool;
-        __syncthreads();                                   // E image free again; wave partials visible
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk's weights (this wave's share) have landed
+        __syncthreads();                                   // E image free again; wave partials and the weights visible
         if (tid < 16) {
             float s = 0.f;
 #pragma unroll
@@ -231,16 +311,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
             p.pool[(size_t)unit * p.mid + ch0 + tid] = s;  // [B][NST][mid]: one partial row per strip
         }
         // (red is rewritten only after the next item's first barrier, which wave 0 reaches after these reads)
+        CCVPE_MI_STAMP(4);
     }
-#undef CCVPE_MI_LOAD_W
+#if CCVPE_MI_CLOCK
+    if (lane == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_mi_clk[i], clk[i]);
+        atomicAdd(&g_mi_clk[5], 1ull);
+        atomicAdd(&g_mi_clk[6], (unsigned long long)(it_hi - it_lo));
+        atomicAdd(&g_mi_clk[7], clkw);
+    }
+#endif
+#undef CCVPE_MI_DMA_W
+#undef CCVPE_MI_DMA_A
 #undef CCVPE_MI_LOAD_TAPS
-#undef CCVPE_MI_LOAD_A
-#undef CCVPE_MI_MTILE
 #undef CCVPE_MI_SCATTER
+#undef CCVPE_MI_VMWAIT
 }
 
-// Geometry for RO output rows per strip (RO a multiple of ty, or the whole image).
-static size_t img_geometry_ro(const MbFrontParams& p, int tx, int ty, int ro, MbImgParams& q) {
+// Geometry for RO output rows per strip (RO a multiple of ty, or the whole image), nwv waves per workgroup and sk 16-channel groups
+// per staging step.
+static size_t img_geometry_ro(const MbFrontParams& p, int tx, int ty, int ro, int nwv, int sk, MbImgParams& q) {
     q.f = p;
     q.RO = ro;
     q.NST = (p.OH + ro - 1) / ro;
@@ -251,28 +341,48 @@ static size_t img_geometry_ro(const MbFrontParams& p, int tx, int ty, int ro, Mb
     const int rows_in = std::min(p.H, (ro - 1) * p.s + p.k);         // input rows of a strip incl. halo
     q.NMT = (rows_in * p.W + 15) / 16;
     q.nchunks = p.mid / 16;
-    return ((size_t)(q.HPa * q.WPa + 1) * EPS + 2 * (size_t)q.NMT * 16 + (size_t)p.k * p.k * 16 + 16 + 8 * 16) * sizeof(float);
+    q.CG = 0;
+    const int kch = p.cinp / 16;
+    return ((size_t)(q.HPa * q.WPa + 1) * EPS + 2 * (size_t)q.NMT * 16 + (size_t)p.k * p.k * 16 + 16 + (size_t)nwv * 16 + (size_t)(kch + nwv * sk) * 256) * sizeof(float);
 }
 
-// Whole image if it fits the LDS of a CU, else the fewest equal strips that do (their halo rows are expanded twice).
-static bool img_geometry(const MbFrontParams& p, int tx, int ty, MbImgParams& q, size_t& lds) {
-    const size_t cap = 150 * 1024;
+// Patch per thread: 4 x 2 outputs (13 LDS reads per output for a 5x5 layer) from 512 pixels up; 4 x 1 on the smaller stride-1 images
+// (blocks 12-15: 32 patches of 4 x 2 keep a quarter of the waves busy in the depthwise phase; 16 reads per output, 65 -> 61 us at batch
+// 32; 2 x 1 measured no better); 2 x 1 for the small stride-2 images.
+static void patch_sel(int oh, int ow, int s, int& tx, int& ty) {
+    if (oh * ow >= 512) { tx = 4; ty = 2; }
+    else if (s == 1) { tx = 4; ty = 1; }
+    else { tx = 2; ty = 1; }
+}
+
+struct ImgPlan {
+    MbImgParams q;
+    size_t lds;
+    int tx, ty, nt, sk;        // patch, threads per workgroup, 16-channel groups per staging step (kch = whole tiles)
+};
+
+// Whole image if it fits the LDS of a CU, else the fewest equal strips that do (their halo rows are expanded twice).  Per strip count:
+// whole-tile staging, else half tiles; two 256-thread workgroups per CU where both fit (out of phase: one's depthwise phase beside the
+// other's expand phase), else one of 512.
+static bool img_plan(const MbFrontParams& p, ImgPlan& pl) {
+    const size_t cap = 158 * 1024;
+    const int kch = p.cinp / 16;
+    patch_sel(p.OH, p.OW, p.s, pl.tx, pl.ty);
     for (int nst = 1; nst <= p.OH; ++nst) {
         int ro = (p.OH + nst - 1) / nst;
-        ro = (ro + ty - 1) / ty * ty;
-        lds = img_geometry_ro(p, tx, ty, ro, q);
-        if (lds <= cap) return (ro - 1) * p.s + p.k <= 4 * ro * p.s;   // not worth it once the halo is 4x the strip
-        if (ro <= ty) break;
+        ro = (ro + pl.ty - 1) / pl.ty * pl.ty;
+        const int hk = (kch + 1) / 2;
+        if (2 * img_geometry_ro(p, pl.tx, pl.ty, ro, 4, kch, pl.q) <= cap) { pl.nt = 256; pl.sk = kch; }
+        else if (kch > 2 && 2 * img_geometry_ro(p, pl.tx, pl.ty, ro, 4, hk, pl.q) <= cap) { pl.nt = 256; pl.sk = hk; }
+        else if (img_geometry_ro(p, pl.tx, pl.ty, ro, 8, kch, pl.q) <= cap) { pl.nt = 512; pl.sk = kch; }
+        else if (kch > 2 && img_geometry_ro(p, pl.tx, pl.ty, ro, 8, hk, pl.q) <= cap) { pl.nt = 512; pl.sk = hk; }
+        else { if (ro <= pl.ty) break; continue; }
+        pl.lds = img_geometry_ro(p, pl.tx, pl.ty, ro, pl.nt / 64, pl.sk, pl.q);
+        return (ro - 1) * p.s + p.k <= 4 * ro * p.s;   // not worth it once the halo is 4x the strip
     }
     return false;
 }
 
-// Patch per thread: 4 x 2 outputs (13 LDS reads per output for a 5x5 layer) - also on a 16 x 16 image, where it keeps only half
-// of a 256-thread workgroup busy but halves the LDS traffic of the 2 x 1 form (27 reads per output); 2 x 1 for the small
-// stride-2 images.
-static void patch_sel(int oh, int ow, int s, int& tx, int& ty) {
-    if (oh * ow >= 512 || s == 1) { tx = 4; ty = 2; } else { tx = 2; ty = 1; }
-}
 // Cin need not be a multiple of 16: the expand weights are zero padded to cinp and the last 16-byte pieces of a pixel then
 // read the first channels of the next pixel (finite activations; past the end the buffer descriptor returns zeros).
 bool mbconv_image_supported(const MbFrontParams& p) {
@@ -281,48 +391,60 @@ bool mbconv_image_supported(const MbFrontParams& p) {
     const bool combo = (p.k == 3 && p.s == 1 && (kch == 2 || kch == 5 || kch == 12)) || (p.k == 5 && p.s == 1 && (kch == 3 || kch == 5 || kch == 7 || kch == 12)) ||
                        (p.k == 5 && p.s == 2 && (kch == 2 || kch == 7)) || (p.k == 3 && p.s == 2 && kch == 3);
     if (!combo) return false;
-    int tx, ty;
-    patch_sel(p.OH, p.OW, p.s, tx, ty);
-    MbImgParams q;
-    size_t lds;
-    if (!img_geometry(p, tx, ty, q, lds)) return false;
+    ImgPlan pl;
+    if (!img_plan(p, pl)) return false;
     // measured (batch 32): a stride-2 layer wider than 128 pixels gets strips of only 4 output rows (1.4x halo rows, items too
     // short for their two barriers): ground block 3 (80 x 160) 0.195 ms fused against 0.182 ms as two launches - left unfused
-    if (q.NST > 1 && p.s == 2 && p.W > 128) return false;
+    if (pl.q.NST > 1 && p.s == 2 && p.W > 128) return false;
     return true;
 }
 
 int mbconv_image_strips(const MbFrontParams& p) {
-    int tx, ty;
-    patch_sel(p.OH, p.OW, p.s, tx, ty);
-    MbImgParams q;
-    size_t lds;
-    return (mbconv_image_supported(p) && img_geometry(p, tx, ty, q, lds)) ? q.NST : 0;
+    ImgPlan pl;
+    return (mbconv_image_supported(p) && img_plan(p, pl)) ? pl.q.NST : 0;
 }
 
-template <int K, int S, int KCH, int TX, int TY, int NT>
-static void launch_img(const MbFrontParams& p, hipStream_t s) {
-    MbImgParams q;
-    size_t lds;
-    img_geometry(p, TX, TY, q, lds);
+template <int K, int S, int KCH, int SK, int TX, int TY, int NT>
+static void launch_img(const MbFrontParams& p, const ImgPlan& pl, hipStream_t s) {
+    const MbImgParams& q = pl.q;
     static LdsAttr attr;
-    auto kern = mbconv_image_kernel<K, S, KCH, TX, TY, NT>;
-    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
+    auto kern = mbconv_image_kernel<K, S, KCH, SK, TX, TY, NT>;
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), pl.lds);
     const int total = std::max(1, p.B * q.NST * q.nchunks);
-    q.CG = 0;
-    hipLaunchKernelGGL(kern, dim3(std::min(total, NT == 512 ? 256 : 512)), dim3(NT), lds, s, q);   // persistent: 8 waves per CU either way
+#if CCVPE_MI_CLOCK
+    static int calls = 0;
+    const bool stamp = ++calls % 8 == 0;
+    if (stamp) { (void)hipStreamSynchronize(s); unsigned long long z[12] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mi_clk), z, sizeof z); }
+#endif
+    hipLaunchKernelGGL(kern, dim3(std::min(total, NT == 512 ? 256 : 512)), dim3(NT), pl.lds, s, q);   // persistent: 8 waves per CU either way
+#if CCVPE_MI_CLOCK
+    if (stamp) {
+        (void)hipStreamSynchronize(s);
+        unsigned long long h[12];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mi_clk), sizeof h);
+        const double w = (double)std::max(1ull, h[5]), tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
+        std::fprintf(stderr, "mbconv_image<%d,%d,%d,%d,%d,%d,%d> %dx%d cin %d mid %d strips %d lds %zu: %.1f items/workgroup, %.0f cycles/wave: set-up %.0f %% expand %.0f %% barrier %.0f %% depthwise %.0f %% tail %.0f %%; %.0f cycles/item, %.0f of them waiting for staged m-tiles\n",
+                     K, S, KCH, SK, TX, TY, NT, p.H, p.W, p.Cin, p.mid, q.NST, pl.lds, (double)h[6] / w, tot / w, 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot,
+                     100.0 * h[4] / tot, tot / std::max(1.0, (double)h[6]), (double)h[7] / std::max(1.0, (double)h[6]));
+    }
+#endif
+}
+
+template <int K, int S, int KCH, int TX, int TY>
+static void launch_img_t(const MbFrontParams& p, const ImgPlan& pl, hipStream_t s) {
+    constexpr int HK = (KCH + 1) / 2;
+    const bool half = pl.sk != KCH;
+    if (!half) { if (pl.nt == 256) launch_img<K, S, KCH, KCH, TX, TY, 256>(p, pl, s); else launch_img<K, S, KCH, KCH, TX, TY, 512>(p, pl, s); }
+    else if constexpr (KCH > 2) { if (pl.nt == 256) launch_img<K, S, KCH, HK, TX, TY, 256>(p, pl, s); else launch_img<K, S, KCH, HK, TX, TY, 512>(p, pl, s); }
 }
 
 template <int K, int S, int KCH>
 static void launch_img_p(const MbFrontParams& p, hipStream_t s) {
-    int tx, ty;
-    patch_sel(p.OH, p.OW, p.s, tx, ty);
-    MbImgParams q;
-    size_t lds;
-    img_geometry(p, tx, ty, q, lds);
-    const bool two = 2 * lds <= 150 * 1024;      // two workgroups of 256 threads per CU
-    if (tx == 4) { if (two) launch_img<K, S, KCH, 4, 2, 256>(p, s); else launch_img<K, S, KCH, 4, 2, 512>(p, s); }
-    else { if (two) launch_img<K, S, KCH, 2, 1, 256>(p, s); else launch_img<K, S, KCH, 2, 1, 512>(p, s); }
+    ImgPlan pl;
+    img_plan(p, pl);
+    if (pl.tx == 4 && pl.ty == 1) { if constexpr (S == 1) launch_img_t<K, S, KCH, 4, 1>(p, pl, s); }
+    else if (pl.tx == 4) launch_img_t<K, S, KCH, 4, 2>(p, pl, s);
+    else launch_img_t<K, S, KCH, 2, 1>(p, pl, s);
 }
 
 void launch_mbconv_image(const MbFrontParams& p, hipStream_t s) {

@@ -12,5 +12,5 @@ objs=""
 for f in $c/*.o; do
   if [ "$(basename $f)" != "${src%.hip}.o" ]; then objs="$objs $f"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libccvpe_${name}.so $objs variants/${name}.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o variants/libccvpe_${name}.so $objs variants/${name}.o
 echo variants/libccvpe_${name}.so
