@@ -165,6 +165,9 @@ int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
                     HIPCHK(hipEventElapsedTime(&t, e0, e1));
                     ms = std::min(ms, t);
                 }
+                static const char* verbose = getenv("CCVPE_TUNE_VERBOSE");   // dev: print every candidate of the launches whose name contains the string
+                if (verbose && op.name.find(verbose) != std::string::npos)
+                    std::fprintf(stderr, "tune %-28s %-28s split %3d: %8.1f us\n", op.name.c_str(), conv_igemm_tile_name(t), split, 500.0 * ms);
                 if (ms < best_ms) { best_ms = ms; best = cfg; }
             }
         }
