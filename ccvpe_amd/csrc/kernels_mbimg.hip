@@ -64,7 +64,9 @@ struct MbImgParams {
 // NT = 512 threads (8 waves, one workgroup per CU) for the large images, 256 (two workgroups per CU, out of phase) when two
 // workgroups' LDS fits.  SK = 16-channel groups per staging step: the whole m-tile (SK = KCH) where the LDS has room for
 // NT / 64 x KCH KB beside the E image, else half of it (two steps per tile).  (Measured and dropped: keeping the input m-tiles of a
-// <= 256-pixel image in registers across all chunks.)
+// <= 256-pixel image in registers across all chunks; TWO chunks per item on the small images of blocks 12-15 - every staged m-tile
+// feeding two MFMA chains, one workgroup of 512 threads per CU whose depthwise phase is one pass of all threads: 0.627 against 0.612 ms
+// for blocks 11-15 at batch 32, the overlap of two out-of-phase workgroups is worth as much as the halved input traffic.)
 template <int K, int S, int KCH, int SK, int TX, int TY, int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mbconv_image_kernel(const MbImgParams q) {
     constexpr int NWV = NT / 64;
