@@ -66,7 +66,9 @@ struct MbImgParams {
 // NT / 64 x KCH KB beside the E image, else half of it (two steps per tile).  (Measured and dropped: keeping the input m-tiles of a
 // <= 256-pixel image in registers across all chunks; TWO chunks per item on the small images of blocks 12-15 - every staged m-tile
 // feeding two MFMA chains, one workgroup of 512 threads per CU whose depthwise phase is one pass of all threads: 0.627 against 0.612 ms
-// for blocks 11-15 at batch 32, the overlap of two out-of-phase workgroups is worth as much as the halved input traffic.)
+// for blocks 11-15 at batch 32, the overlap of two out-of-phase workgroups is worth as much as the halved input traffic; the two halves of a
+// tile as a ring - a half requested for the next tile as soon as it is read, `vmcnt(other half)` waits - 2.361 against 2.353 ms over the 29
+// launches: spreading the requests changes nothing.)
 template <int K, int S, int KCH, int SK, int TX, int TY, int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mbconv_image_kernel(const MbImgParams q) {
     constexpr int NWV = NT / 64;
