@@ -43,11 +43,15 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
     int lo, hi;
     static_pad(3, 2, lo, hi);
     int ch = conv_out(H, 3, 2), cw = conv_out(W, 3, 2);
-    Tensor cur = pl.alloc(B, ch, cw, 32);
-    {
-        StemParams sp{};
-        sp.B = B; sp.H = H; sp.W = W; sp.OH = ch; sp.OW = cw; sp.pad_t = lo; sp.pad_l = lo; sp.circular = circular;
-        sp.w = ew.stem_w; sp.bias = ew.stem_b;
+    // stem + the depthwise conv of block 0 in one launch (block 0 has no expand conv; kernels_encoder.hip): the half-resolution 32-channel
+    // stem output never reaches HBM.  CCVPE_STEM_DW=0: two launches (read per plan: tests toggle it)
+    const bool stem_dw = !(getenv("CCVPE_STEM_DW") && std::atoi(getenv("CCVPE_STEM_DW")) == 0) && B0[0].e == 1 && B0[0].k == 3 && B0[0].s == 1 && B0[0].cin == 32;
+    StemParams stem_sp{};
+    stem_sp.B = B; stem_sp.H = H; stem_sp.W = W; stem_sp.OH = ch; stem_sp.OW = cw; stem_sp.pad_t = lo; stem_sp.pad_l = lo; stem_sp.circular = circular;
+    stem_sp.w = ew.stem_w; stem_sp.bias = ew.stem_b;
+    Tensor cur = stem_dw ? Tensor{} : pl.alloc(B, ch, cw, 32);
+    if (!stem_dw) {
+        const StemParams sp = stem_sp;
         Tensor o = cur;
         pl.add(tag + ".stem", {o}, [sp, o, is_grd](const Ctx& c) {
             StemParams q = sp; q.in = is_grd ? c.grd : c.sat; q.out = c.ptr(o);
@@ -73,9 +77,17 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         const bool fused = image || (b.e != 1 && bw.exp_lin != nullptr && mbconv_front_supported(b.k, b.s, b.cin, mid) &&
                            (h->fuse_mbconv == 2 || (h->fuse_mbconv == 1 && mbconv_front_profitable(b.k))));
         Tensor d = pl.alloc(B, oh, ow, mid);
-        const int S = image ? mbconv_image_strips(mp) : fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid, b.k, b.s);
+        const bool with_stem = stem_dw && i == 0;
+        const int S = with_stem ? stem_dw_tiles(oh, ow) : image ? mbconv_image_strips(mp) : fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid, b.k, b.s);
         Tensor pool = pl.alloc(B, 1, S, mid);
-        if (fused) {
+        if (with_stem) {
+            StemDwParams sd{};
+            sd.st = stem_sp; sd.wd = bw.dw_w; sd.bd = bw.dw_b;
+            pl.add(tag + ".stem_b0dw", {d, pool}, [=](const Ctx& c) {
+                StemDwParams q = sd; q.st.in = is_grd ? c.grd : c.sat; q.out = c.ptr(d); q.pool_partial = c.ptr(pool);
+                launch_stem_dw(q, c.stream);
+            }, 2.0 * B * ch * cw * 32 * 27 + 2.0 * B * oh * ow * mid * 9, 4.0 * B * (3.0 * H * W + 32.0 * oh * ow));
+        } else if (fused) {
             pl.add(bn + ".expand_dw", {xin, d, pool}, [=](const Ctx& c) {
                 MbFrontParams q = mp; q.x = c.ptr(xin); q.out = c.ptr(d); q.pool = c.ptr(pool);
                 if (image) launch_mbconv_image(q, c.stream); else launch_mbconv_front(q, c.stream);

@@ -170,6 +170,17 @@ struct StemParams {
 };
 void launch_stem(const StemParams& p, hipStream_t s);
 
+// Stem + block 0's depthwise conv in one launch (block 0 has no expand conv: its depthwise conv reads the stem output directly)
+struct StemDwParams {
+    StemParams st;             // st.out unused
+    const float* wd;           // [9][32] depthwise taps, BN folded
+    const float* bd;           // [32]
+    float* out;                // NHWC [B,OH,OW,32]: swish(dw(swish(stem)))
+    float* pool_partial;       // [B][S][32] partial sums of `out`, S = stem_dw_tiles
+};
+int stem_dw_tiles(int OH, int OW);   // pooling partial rows per sample
+void launch_stem_dw(const StemDwParams& p, hipStream_t s);
+
 struct DwParams {
     const float* in;           // NHWC [B,H,W,C]
     int B, H, W, C, OH, OW;

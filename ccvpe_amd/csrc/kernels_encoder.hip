@@ -179,6 +179,205 @@ void launch_stem(const StemParams& p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stem + the depthwise conv of block 0 (round 3).  Block 0 of EfficientNet-B0 has expand ratio 1 (model.py:103: no expand conv), so its
+// 3x3 / stride-1 depthwise conv (model.py:108-110) reads the stem output (model.py:314: conv_stem + bn0 + swish) directly.  As two
+// launches the 32-channel half-resolution tensor is written and read back (268 MB each way for the aerial encoder at batch 32); both are
+// bound by that traffic (4.4 / 5.2 TB/s).  Here a workgroup owns 32 x 8 outputs of the depthwise conv: it computes the 34 x 10 stem
+// pixels they depend on from a 69 x 21 x 3 input patch in LDS (the halo is recomputed: 1.33x of the stem's FMAs), keeps them in LDS
+// (zero outside the stem output where the reference pads with zeros, wrapped columns for the circular encoder: the patch fetch wraps
+// the INPUT column, which is the same thing since W = 2 OW), runs the depthwise taps from there and stores only its result plus one
+// pooling partial row per tile.  Per output the FMA order of both convs is the one of the separate kernels (same bits up to the
+// squeeze-excite pooling order).  Thread = (channel quad, column); the stem phase computes 10 rows per thread plus, for 160 threads, one
+// pixel of the two halo columns 32 / 33; the next tile's patch arrives by LDS-DMA under the depthwise phase.
+// ------------------------------------------------------------------------------------------------
+static constexpr int SD_TW = 32, SD_TH = 8;
+static constexpr int SD_SW = SD_TW + 2, SD_SH = SD_TH + 2;               // stem pixels a tile needs
+static constexpr int SD_PW = 2 * SD_SW + 1, SD_PH = 2 * SD_SH + 1;       // input patch
+static constexpr int SD_PITCH = SD_PW + 2;
+
+__global__ __launch_bounds__(256, 2) void stem_dw_kernel(const StemDwParams q) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const StemParams& p = q.st;
+    extern __shared__ __attribute__((aligned(16))) float sd_smem[];
+    constexpr int PATCH = (3 * SD_PH * SD_PITCH + 3) & ~3;
+    float* patch = sd_smem;                                           // [3][SD_PH][SD_PITCH]
+    float* st = sd_smem + PATCH;                                      // [SD_SH][SD_SW][32] stem output (+ swish), halo included
+    float* red = st + SD_SH * SD_SW * 32;                             // [4][32]
+    float* wds = red + 4 * 32;                                        // [9][32] depthwise taps
+    float* wst = wds + 9 * 32;                                        // [27][32] stem weights: 108 registers if held per thread (the kernel then spills);
+                                                                      // from LDS the nine vectors of one input channel at a time
+    const int tid = threadIdx.x;
+    const int cg = tid & 7, col = tid >> 3;                           // channel quad, tile column
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const f32x4s bias = *reinterpret_cast<const f32x4s*>(p.bias + cg * 4);
+    const f32x4s bd = *reinterpret_cast<const f32x4s*>(q.bd + cg * 4);
+    for (int i = tid; i < 9 * 32; i += 256) wds[i] = q.wd[i];      // (visible after the first barrier of the tile loop)
+    for (int i = tid; i < 27 * 32; i += 256) wst[i] = p.w[i];
+    const int tiles_x = (p.OW + SD_TW - 1) / SD_TW, tiles_y = (p.OH + SD_TH - 1) / SD_TH;
+    const int tps = tiles_x * tiles_y;                                // tiles per sample = pooling partial rows
+    const int tiles = p.B * tps;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, (unsigned)((size_t)p.B * 3 * p.H * p.W * 4), 0x00020000);
+    // The input patch of a tile arrives by LDS-DMA, requested when the previous tile's stem phase is over (the patch is read there only)
+    // and landing under its depthwise phase: a (channel, row) of 69 floats is two instructions (lanes = columns 0..63 and 64..68); the
+    // column of a lane is wrapped / bounds-checked once per tile, rows outside the image and columns outside a non-circular image get
+    // the out-of-range offset (the descriptor returns zeros).  No registers held across the tile, no per-element index arithmetic.
+    auto fetch = [&](int tl) {
+        float* dst = patch;
+        const int b = tl / tps;
+        const int r = tl - b * tps;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int iy0 = (ty * SD_TH - 1) * 2 - p.pad_t, ix0 = (tx * SD_TW - 1) * 2 - p.pad_l;
+        unsigned xo[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int ix = ix0 + h * 64 + lane;
+            if (p.circular) { if (ix < 0) ix += p.W; else if (ix >= p.W) ix -= p.W; }
+            const bool ok = h * 64 + lane < SD_PW && (unsigned)ix < (unsigned)p.W;
+            xo[h] = ok ? (unsigned)ix * 4u : 0x80000000u;
+        }
+        for (int pr = wave; pr < 3 * SD_PH; pr += 4) {                // (channel, patch row) pairs of this wave
+            const int c = pr / SD_PH, y = pr - c * SD_PH;
+            const int iy = iy0 + y;
+            const bool rok = (unsigned)iy < (unsigned)p.H;
+            const unsigned rowb = (unsigned)((((size_t)b * 3 + c) * p.H + (rok ? iy : 0)) * p.W) * 4u;
+            float* d = dst + pr * SD_PITCH;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr)d, 4, rok ? xo[0] : 0x80000000u, rowb, 0, 0);
+            // (only the lanes that hold a column: an out-of-range lane still WRITES its zero, here into the next row of the patch)
+            if (lane < SD_PW - 64) __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr)(d + 64), 4, rok ? xo[1] : 0x80000000u, rowb, 0, 0);
+        }
+    };
+    // one stem pixel (row r, column c of the halo tile) from the patch: taps in the order of stem_tile_kernel (c, ky, kx ascending)
+    auto stem_px = [&](const float* patch, int r, int c) {
+        f32x4s a = bias;
+        const float* pp = patch + 2 * c;
+#pragma unroll 1
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* row = pp + (ch * SD_PH + 2 * r + ky) * SD_PITCH;
+                const float* wr = wst + ((ch * 3 + ky) * 3) * 32 + cg * 4;
+                a = __builtin_elementwise_fma(f32x4s{row[0], row[0], row[0], row[0]}, *reinterpret_cast<const f32x4s*>(wr), a);
+                a = __builtin_elementwise_fma(f32x4s{row[1], row[1], row[1], row[1]}, *reinterpret_cast<const f32x4s*>(wr + 32), a);
+                a = __builtin_elementwise_fma(f32x4s{row[2], row[2], row[2], row[2]}, *reinterpret_cast<const f32x4s*>(wr + 64), a);
+            }
+        return a;
+    };
+    if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int b = tile / tps;
+        const int tr = tile - b * tps;
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int oy0 = ty * SD_TH, ox0 = tx * SD_TW;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's share of the patch has landed
+        __syncthreads();                                              // ... everybody's; the previous tile's readers are done with the stem tile
+        // ---- stem: rows 0..9 of halo column `col` (patch rows shared between the output rows they feed) ----
+        {
+            f32x4s acc[SD_SH];
+#pragma unroll
+            for (int i = 0; i < SD_SH; ++i) acc[i] = bias;
+            const float* pp = patch + 2 * col;
+#pragma unroll 1
+            for (int c = 0; c < 3; ++c) {                             // (a real loop: one input channel's nine weight vectors in registers at a time)
+                f32x4s w[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const f32x4s*>(wst + (c * 9 + t) * 32 + cg * 4);
+                const float* pc = pp + c * SD_PH * SD_PITCH;
+#pragma unroll
+                for (int y = 0; y < SD_PH; ++y) {
+                    const float v0 = pc[y * SD_PITCH], v1 = pc[y * SD_PITCH + 1], v2 = pc[y * SD_PITCH + 2];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        if ((y - ky) < 0 || ((y - ky) & 1) || (y - ky) / 2 >= SD_SH) continue;
+                        const int i = (y - ky) / 2;
+                        acc[i] = __builtin_elementwise_fma(f32x4s{v0, v0, v0, v0}, w[ky * 3], acc[i]);
+                        acc[i] = __builtin_elementwise_fma(f32x4s{v1, v1, v1, v1}, w[ky * 3 + 1], acc[i]);
+                        acc[i] = __builtin_elementwise_fma(f32x4s{v2, v2, v2, v2}, w[ky * 3 + 2], acc[i]);
+                    }
+                }
+            }
+            const int sx = ox0 - 1 + col;
+            const bool colok = p.circular || (unsigned)sx < (unsigned)p.OW;
+#pragma unroll
+            for (int i = 0; i < SD_SH; ++i) {
+                const int sy = oy0 - 1 + i;
+                const bool ok = colok && (unsigned)sy < (unsigned)p.OH;
+                f32x4s o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = ok ? swishf(acc[i][e]) : 0.f;
+                *reinterpret_cast<f32x4s*>(st + (i * SD_SW + col) * 32 + cg * 4) = o;
+            }
+        }
+        if (tid < 8 * 2 * SD_SH) {                                    // the two halo columns past the 32 thread columns: one pixel per thread
+            const int e2 = tid >> 3, r = e2 >> 1, c = SD_TW + (e2 & 1);
+            const f32x4s a = stem_px(patch, r, c);
+            const int sx = ox0 - 1 + c, sy = oy0 - 1 + r;
+            const bool ok = (p.circular || (unsigned)sx < (unsigned)p.OW) && (unsigned)sy < (unsigned)p.OH;
+            f32x4s o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ok ? swishf(a[e]) : 0.f;
+            *reinterpret_cast<f32x4s*>(st + (r * SD_SW + c) * 32 + cg * 4) = o;
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);    // the patch is free: the next tile's lands under the depthwise phase
+        // ---- depthwise 3x3 from the stem tile: 8 outputs of column `col`; per output ky, kx ascending as in depthwise_kernel ----
+        f32x4s pool = {0.f, 0.f, 0.f, 0.f};
+        {
+            f32x4s wd[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wd[t] = *reinterpret_cast<const f32x4s*>(wds + t * 32 + cg * 4);
+            f32x4s acc[SD_TH];
+#pragma unroll
+            for (int i = 0; i < SD_TH; ++i) acc[i] = bd;
+#pragma unroll
+            for (int r = 0; r < SD_SH; ++r) {
+                f32x4s v[3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) v[kx] = *reinterpret_cast<const f32x4s*>(st + (r * SD_SW + col + kx) * 32 + cg * 4);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int i = r - ky;
+                    if (i < 0 || i >= SD_TH) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc[i] = __builtin_elementwise_fma(v[kx], wd[ky * 3 + kx], acc[i]);   // (v_pk_fma_f32: per element the same fused operation)
+                }
+            }
+            const int ox = ox0 + col;
+            if (ox < p.OW) {
+#pragma unroll
+                for (int i = 0; i < SD_TH; ++i) {
+                    const int oy = oy0 + i;
+                    if (oy >= p.OH) break;
+                    f32x4s o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = swishf(acc[i][e]);
+                    pool += o;
+                    *reinterpret_cast<f32x4s*>(q.out + (((size_t)b * p.OH + oy) * p.OW + ox) * 32 + cg * 4) = o;
+                }
+            }
+        }
+        // pooling partial of the tile: columns of a wave (lane bits 3..5), then the four waves through LDS; fixed order -> deterministic
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pool[e] += __shfl_xor(pool[e], off);
+        if (lane < 8) *reinterpret_cast<f32x4s*>(red + wave * 32 + lane * 4) = pool;
+        __syncthreads();
+        if (tid < 32) q.pool_partial[((size_t)b * tps + tr) * 32 + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+    }
+}
+
+int stem_dw_tiles(int OH, int OW) { return ((OW + SD_TW - 1) / SD_TW) * ((OH + SD_TH - 1) / SD_TH); }
+
+void launch_stem_dw(const StemDwParams& q, hipStream_t s) {
+    const int tiles = q.st.B * stem_dw_tiles(q.st.OH, q.st.OW);
+    const size_t lds = (size_t)(((3 * SD_PH * SD_PITCH + 3) & ~3) + SD_SH * SD_SW * 32 + 4 * 32 + 9 * 32 + 27 * 32) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL(stem_dw_kernel, dim3(std::min(tiles, 512)), dim3(256), lds, s, q);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Depthwise k x k (k = 3 | 5), stride 1 | 2, static zero / horizontal-circular padding, BN + swish,
 // plus per-(sample, strip-lane, channel) partial sums for the squeeze-excite average pool.
 // thread = (4 channels, patch of TX x TY output pixels).  The thread keeps its k*k filter taps (4 channels each)
