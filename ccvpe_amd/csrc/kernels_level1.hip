@@ -8,12 +8,13 @@
 // an N=16 GEMM with 5 K tiles (prologue/epilogue dominated).  Here one workgroup owns a 16x16 output
 // tile: the 10x10 input pixels it depends on are staged in LDS once, the transposed conv (a [100 x CX] x
 // [CX x 64] GEMM) and the 3x3 conv (a [324 x 144] x [144 x 16] GEMM whose A operand is gathered from the
-// LDS tile at 9 shifted positions) run on v_mfma_f32_16x16x4_f32, the final 16->{1,2} conv on the VALU,
-// and only the 1-2 output channels leave the chip.  Zero padding of both 3x3 convs is applied where the
+// LDS tile at 9 shifted positions) run on v_mfma_f32_16x16x4_f32, the final 16->{1,2} conv as per-tap dot products on
+// the same MFMAs plus nine adds per output (round 3; on the VALU before), and only the 1-2 output channels leave the chip.  Zero padding of both 3x3 convs is applied where the
 // reference applies it: intermediate pixels outside the 512x512 image are forced to 0 (not bias).
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdio>
 
 namespace ccvpe {
 
@@ -28,8 +29,15 @@ static constexpr int DSINK = DT + 2;  // sink rows behind the D tile: offset (dy
 static constexpr int AROWS = ((AT * AT + 15) / 16) * 16;   // A tile rows incl. the padding rows of the last m-tile
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef CCVPE_L1_TAIL_W_LDS
-#define CCVPE_L1_TAIL_W_LDS 1   // 0: the last conv's weights from global memory (rounds 1-2)
+
+#ifndef CCVPE_L1_CLOCK
+#define CCVPE_L1_CLOCK 0   // dev builds (tools/build_variant.sh): 1 = every wave sums s_memtime per stage (input -> LDS + barrier, deconv, barrier, conv_a, barrier, tail conv + stores, end barrier)
+#endif
+#if CCVPE_L1_CLOCK
+__device__ unsigned long long g_l1_clk[10];
+#define CCVPE_L1_STAMP(i_) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); clk[i_] += t_ - tprev; tprev = t_; }
+#else
+#define CCVPE_L1_STAMP(i_)
 #endif
 
 static constexpr int KCH_MAX = 4;     // input channels <= 64 (16 per k-chunk); the host falls back to the unfused path beyond
@@ -68,13 +76,19 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
     // the two epilogues are tabulated (stage 1) or affine (stage 2); tiles whose halo lies fully inside the image
     // (88 % of them) also skip every bounds test.
     if (tid < 112) dtab[tid] = tid < XT * XT ? ((2 * (tid / XT)) * DT + 2 * (tid % XT)) * PS : DT * DT * PS;
-#if CCVPE_L1_TAIL_W_LDS
-    // weights of the last conv -> LDS once (round 3): read from global memory inside the persistent loop they are VECTOR loads (the kernel
-    // stores to global memory, so hipcc may not scalarise them) with an `s_waitcnt vmcnt(0)` behind every tap - nine exposed L2 round
-    // trips per tile.  From LDS every lane reads the same address (a broadcast, one bank access) under lgkmcnt.
-    float* wts = reinterpret_cast<float*>(dtab + 112);            // [9][COUT][16]
-    for (int i = tid; i < 9 * COUT * 16; i += 256) wts[i] = p.wt[i];
-#endif
+    // Last conv (16 -> COUT, 3x3) in two steps (round 3): P[pixel][tap, co] = sum_c A[pixel][c] wt[tap][co][c] for every pixel of the 18 x 18
+    // conv_a tile - a [324 x 16] x [16 x 9 COUT] GEMM whose B operand is the conv_a accumulator AS IT STANDS in registers (lane = pixel,
+    // 4 channels: exactly the operand layout), 4 MFMAs per 16 pixels and 16 (tap, co) columns - and out[y][x][co] = bt + sum_tap P[(y + dy,
+    // x + dx)][tap, co]: nine LDS reads and adds per output.  The P tile takes the A tile's place in LDS (18 of its 20 floats per pixel).
+    // Before: 72 COUT packed FMAs, 36 16-byte A reads and 36 COUT weight reads per output pixel on the vector pipe - a quarter of the
+    // kernel's time (in-kernel stamps, CCVPE_L1_CLOCK).
+    constexpr int NPT = (9 * COUT + 15) / 16;                     // 16-column tiles of P
+    f32x4 wtf[NPT];                                               // A fragments: wt[n = 16 nt + (lane & 15)][4 (lane >> 4) + e], n = tap * COUT + co
+#pragma unroll
+    for (int nt = 0; nt < NPT; ++nt) {
+        const int n = nt * 16 + (lane & 15);
+        wtf[nt] = n < 9 * COUT ? *reinterpret_cast<const f32x4*>(p.wt + (size_t)n * 16 + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int kch = CXP >> 4;
     // deconv weights: wave w owns output parity (dy,dx) = (w>>1, w&1); B operand of k-chunk kc, MFMA j is
     // Wd[n = w*16 + (lane&15)][16*kc + 4*(lane>>4) + j]
@@ -89,9 +103,6 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
     // channel-major accumulators (weights are the A operand of the MFMAs): a lane holds channels 4 (lane >> 4) .. + 3 of ONE pixel
     const f32x4 bd = *reinterpret_cast<const f32x4*>(p.bd + 4 * (lane >> 4));
     const f32x4 ba = *reinterpret_cast<const f32x4*>(p.ba + 4 * (lane >> 4));
-#if !CCVPE_L1_TAIL_W_LDS
-    const float* __restrict__ wt = p.wt;   // [9][COUT][16]
-#endif
 
     // X tile staging: float4 item i = tid + it*256 -> pixel i / c4n, channels 4*(i % c4n)
     const int c4n = CXP >> 2;
@@ -125,7 +136,14 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
     const size_t hw = (size_t)H * W;
     constexpr int NMT = (AT * AT + 15) / 16;   // 21
 
+#if CCVPE_L1_CLOCK
+    unsigned long long clk[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    int ntiles = 0;
+#endif
     while (true) {
+#if CCVPE_L1_CLOCK
+        ++ntiles;
+#endif
         const int b = tile / (tiles_x * tiles_y);
         const int rem = tile - b * (tiles_x * tiles_y);
         const int Y0 = (rem / tiles_x) * T, X0 = (rem % tiles_x) * T;
@@ -136,6 +154,7 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
         for (int it = 0; it < XI_MAX; ++it)
             if (x_lds[it] >= 0) *reinterpret_cast<f32x4*>(Xs + x_lds[it]) = xv[it];
         __syncthreads();
+        CCVPE_L1_STAMP(0);
         const int tile_n = tile + stride;
         const bool have_n = tile_n < t_end;
         if (have_n) { CCVPE_L1_LOAD_X(tile_n); }
@@ -196,7 +215,9 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
                 }
             }
         }
+        CCVPE_L1_STAMP(1);
         __syncthreads();
+        CCVPE_L1_STAMP(2);
 
         // ---- stage 2: conv3x3 16->16 + ReLU on the 18x18 halo tile: 21 m-tiles of 16 pixels, 36 MFMAs each ----
         for (int mt0 = wave; mt0 < NMT; mt0 += 8) {
@@ -246,37 +267,32 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
                     const bool in = q < AT * AT && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
                     if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                *reinterpret_cast<f32x4*>(As + q * PS + 4 * (lane >> 4)) = v;
-            }
-        }
-        __syncthreads();
-
-        // ---- stage 3: conv3x3 16->COUT on the VALU, one output pixel per thread, NCHW store ----
-        // channel pairs on v_pk_fma_f32 (half the VALU slots); the weights are uniform and stay in scalar registers
-        f32x2 o2[COUT];
+                // the last conv's per-tap dot products of this pixel: v is the B operand as it stands
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) o2[c] = f32x2{p.bt[c], 0.f};
+                for (int nt = 0; nt < NPT; ++nt) {
+                    f32x4 pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float* ap = As + ((oy + t / 3) * AT + ox + t % 3) * PS;
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ap + c4 * 4);
-#pragma unroll
-                for (int c = 0; c < COUT; ++c) {
-#if CCVPE_L1_TAIL_W_LDS
-                    const float* wp = wts + (t * COUT + c) * 16 + c4 * 4;
-#else
-                    const float* wp = wt + (t * COUT + c) * 16 + c4 * 4;
-#endif
-                    o2[c] = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{wp[0], wp[1]}, o2[c]);
-                    o2[c] = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{wp[2], wp[3]}, o2[c]);
+                    for (int e = 0; e < 4; ++e) pa = __builtin_amdgcn_mfma_f32_16x16x4f32(wtf[nt][e], v[e], pa, 0, 0, 0);
+                    // columns 16 nt + 4 (lane >> 4) .. + 3 of pixel q; 9 COUT <= 18 columns are real: the second tile keeps two
+                    if (nt == 0) *reinterpret_cast<f32x4*>(As + q * PS + 4 * (lane >> 4)) = pa;
+                    else if ((lane >> 4) == 0) *reinterpret_cast<f32x2*>(As + q * PS + 16) = f32x2{pa[0], pa[1]};
                 }
             }
         }
+        CCVPE_L1_STAMP(3);
+        __syncthreads();
+        CCVPE_L1_STAMP(4);
+
+        // ---- stage 3: out = bias + the nine taps' dot products of the shifted pixels, one output pixel per thread, NCHW store ----
         float o[COUT];
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) o[c] = o2[c].x + o2[c].y;
+        for (int c = 0; c < COUT; ++c) o[c] = p.bt[c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float* pp = As + ((oy + t / 3) * AT + ox + t % 3) * PS + t * COUT;
+            if (COUT == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(pp); o[0] += v.x; o[COUT - 1] += v.y; }
+            else o[0] += pp[0];
+        }
         const size_t opix = (size_t)(Y0 + oy) * W + X0 + ox;
         if (p.raw) {
 #pragma unroll
@@ -293,10 +309,19 @@ __global__ __launch_bounds__(256) void level1_kernel(const Level1Params p) {
 #pragma unroll
         for (int c = 0; c < COUT; ++c) p.out[((size_t)b * COUT + c) * hw + opix] = o[c];
 
+        CCVPE_L1_STAMP(5);
         if (!have_n) break;
         __syncthreads();   // the A tile (aliasing Xs) is fully consumed before the next X tile lands
+        CCVPE_L1_STAMP(6);
         tile = tile_n;
     }
+#if CCVPE_L1_CLOCK
+    if (lane == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_l1_clk[i], clk[i]);
+        atomicAdd(&g_l1_clk[7], 1ull);
+        atomicAdd(&g_l1_clk[8], (unsigned long long)ntiles);
+    }
+#endif
 #undef CCVPE_L1_LOAD_X
 }
 
@@ -306,13 +331,18 @@ size_t level1_lds_bytes(int cxp, int cout) {
     const int XS = cxp + 4;
     const size_t r0f = std::max<size_t>((size_t)XT * XT * XS, (size_t)AROWS * PS);
     (void)cout;
-    return (r0f + (size_t)(DT * DT + DSINK) * PS + 112 + 9 * 2 * 16) * sizeof(float);   // + the tail conv's weights (<= 2 output channels)
+    return (r0f + (size_t)(DT * DT + DSINK) * PS + 112) * sizeof(float);
 }
 
 void launch_level1(const Level1Params& p, hipStream_t s) {
     const size_t lds = level1_lds_bytes(p.cxp, p.cout);
     const int tiles = (p.W / T) * (p.H / T) * p.B;
     dim3 grid(std::min(tiles, 2 * 256));   // persistent: two workgroups per CU
+#if CCVPE_L1_CLOCK
+    static int calls = 0;
+    const bool stamp = ++calls % 4 == 0;
+    if (stamp) { (void)hipStreamSynchronize(s); unsigned long long z[10] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_l1_clk), z, sizeof z); }
+#endif
     if (p.cout == 1) {
         static LdsAttr attr1;
         ensure_dynamic_lds(attr1, reinterpret_cast<const void*>(level1_kernel<1>), lds);
@@ -322,6 +352,17 @@ void launch_level1(const Level1Params& p, hipStream_t s) {
         ensure_dynamic_lds(attr2, reinterpret_cast<const void*>(level1_kernel<2>), lds);
         hipLaunchKernelGGL(level1_kernel<2>, grid, dim3(256), lds, s, p);
     }
+#if CCVPE_L1_CLOCK
+    if (stamp) {
+        (void)hipStreamSynchronize(s);
+        unsigned long long h[10];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_l1_clk), sizeof h);
+        double tot = 0;
+        for (int i = 0; i < 7; ++i) tot += (double)h[i];
+        std::fprintf(stderr, "level1<%d> cx %d: %.0f cycles/tile and wave: input->LDS+barrier %.0f %% deconv %.0f %% barrier %.0f %% conv_a %.0f %% barrier %.0f %% tail conv %.0f %% end barrier %.0f %%\n",
+                     p.cout, p.cx, tot / std::max(1.0, (double)h[8]), 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, 100 * h[6] / tot);
+    }
+#endif
 }
 
 }  // namespace ccvpe
