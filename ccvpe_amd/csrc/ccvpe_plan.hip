@@ -389,6 +389,13 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
 
     Tensor x = dmap;
     Tensor loc_mid;
+    // The preparation launch of every matching level (rolled descriptor / Gm, Mk) depends on the ground descriptor only: the six of them are
+    // moved in front of the first matching level, where the localisation stream otherwise waits for the aerial encoder (batch 1: ~40 us off the
+    // critical path).  CCVPE_MATCH_PREP_EARLY=0: inside each level's launch as before.
+    const bool prep_early = !(getenv("CCVPE_MATCH_PREP_EARLY") && std::atoi(getenv("CCVPE_MATCH_PREP_EARLY")) == 0);
+    size_t first_match_op = (size_t)-1;
+    std::vector<std::function<void(const Ctx&)>> prep_fns;
+    std::vector<std::vector<Tensor>> prep_uses;
     for (int k = 0; k < 6; ++k) {   // matching level k+1 feeds decoder level 6-k
         MatchParams mp{};
         const int hw = (8 << k) * (8 << k);
@@ -419,20 +426,33 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
         const int R = mp.R;
         std::vector<Tensor> uses = {xin, desc, lin, ggs};
         if (first) uses.push_back(ori_in6);
-        pl.add("match" + std::to_string(k + 1), uses, [=](const Ctx& c) {
+        mp.prep_done = prep_early ? 1 : 0;
+        auto fill = [=](const Ctx& c) {        // the same parameters for the preparation and the main launch: both pick the same form
             MatchParams q = mp;
             q.x = c.ptr(xin); q.g = c.ptr(desc) + goff;
             q.ms = c.out.matching_score[k];
             q.cat_max = c.ptr(lin);
             q.cat_all = first ? c.ptr(ori_in6) : nullptr;
             q.gg_scratch = c.ptr(ggs);
-            launch_match(q, c.stream);
-        }, 4.0 * B * hw * (double)R * L[k], 4.0 * B * hw * (2.0 * C + R + 8));
+            return q;
+        };
+        if (first_match_op == (size_t)-1) first_match_op = pl.ops.size();
+        if (prep_early) {
+            prep_fns.push_back([=](const Ctx& c) { launch_match_prep(fill(c), c.stream); });
+            prep_uses.push_back({desc, ggs});
+        }
+        pl.add("match" + std::to_string(k + 1), uses, [=](const Ctx& c) { launch_match(fill(c), c.stream); },
+               4.0 * B * hw * (double)R * L[k], 4.0 * B * hw * (2.0 * C + R + 8));
         pl.taps["loc_in" + std::to_string(6 - k)] = {lin, 0, lin.C};
         if (k == 5 && h->fuse_level1) { plan_level1_fused(h->loc, lin, vs.loc[5].din, 1, false, Tensor{}, "loc1"); break; }
         Tensor o = plan_level(h->loc, vs.loc, k, lin, loc_cat[k], "loc" + std::to_string(6 - k));
         if (k < 5) { pl.taps["loc_level" + std::to_string(6 - k)] = {o, 0, o.C}; x = o; }
         else loc_mid = o;
+    }
+    if (!prep_fns.empty()) {   // the preparation launches go in front of the first matching level
+        const size_t n0 = pl.ops.size();
+        for (size_t i = 0; i < prep_fns.size(); ++i) pl.add("match" + std::to_string(i + 1) + ".prep", prep_uses[i], prep_fns[i], 0.0, 0.0);
+        std::rotate(pl.ops.begin() + first_match_op, pl.ops.begin() + n0, pl.ops.end());
     }
     if (!h->fuse_level1) {
         Tensor m = loc_mid;

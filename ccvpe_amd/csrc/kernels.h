@@ -264,8 +264,12 @@ struct MatchParams {
     float* cat_all;  int cat_all_ld;  int rpad;
     int P;                     // pixels per block (power of two, divides HW)
     float* gg_scratch;         // [B][match_scratch_floats(C)]: rolled descriptor of the small-C register form / Gm, Mk of the MFMA form (null = LDS form only)
+    int prep_done;             // 1: launch_match_prep already ran on these parameters (launch_match then skips its preparation launch)
 };
 void launch_match(const MatchParams& p, hipStream_t s);
+// The preparation launch alone (rolled descriptor / Gm, Mk into gg_scratch): it depends on the ground descriptor only, so a plan may issue it
+// long before the aerial features exist.  Same form decision as launch_match when given the same parameters; no launch for the LDS form.
+void launch_match_prep(const MatchParams& p, hipStream_t s);
 int match_pixels_per_block(int HW, int C);
 size_t match_scratch_floats(int C);   // per-sample floats of MatchParams::gg_scratch
 

@@ -352,10 +352,19 @@ int match_pixels_per_block(int HW, int C) {
     return P;
 }
 
-void launch_match(const MatchParams& p, hipStream_t s) {
+static bool match_use_mfma(const MatchParams& p) {
     static const bool no_mfma = getenv("CCVPE_MATCH_MFMA") && std::atoi(getenv("CCVPE_MATCH_MFMA")) == 0;
-    if (!no_mfma && match_mfma_supported(p)) {
-        hipLaunchKernelGGL(match_mfma_prep_kernel, dim3(p.B, 8), dim3(256), 0, s, p, p.gg_scratch);
+    return !no_mfma && match_mfma_supported(p);
+}
+
+void launch_match_prep(const MatchParams& p, hipStream_t s) {
+    if (match_use_mfma(p)) hipLaunchKernelGGL(match_mfma_prep_kernel, dim3(p.B, 8), dim3(256), 0, s, p, p.gg_scratch);
+    else if (p.gg_scratch && match_small_supported(p)) hipLaunchKernelGGL(match_prep_kernel, dim3(p.B), dim3(256), 0, s, p, p.gg_scratch);
+}
+
+void launch_match(const MatchParams& p, hipStream_t s) {
+    if (match_use_mfma(p)) {
+        if (!p.prep_done) hipLaunchKernelGGL(match_mfma_prep_kernel, dim3(p.B, 8), dim3(256), 0, s, p, p.gg_scratch);
         const size_t lds = ((size_t)16 * (p.C + 4) + 4 * 2 * 2 * 256 + 32 * 16) * sizeof(float);
         static LdsAttr attr;
         if (lds > 64 * 1024) ensure_dynamic_lds(attr, reinterpret_cast<const void*>(match_mfma_kernel), lds);
@@ -363,7 +372,7 @@ void launch_match(const MatchParams& p, hipStream_t s) {
         return;
     }
     if (p.gg_scratch && match_small_supported(p)) {
-        hipLaunchKernelGGL(match_prep_kernel, dim3(p.B), dim3(256), 0, s, p, p.gg_scratch);
+        if (!p.prep_done) hipLaunchKernelGGL(match_prep_kernel, dim3(p.B), dim3(256), 0, s, p, p.gg_scratch);
         dim3 grid((p.HW + 255) / 256, p.B);
         if (p.C == 32) hipLaunchKernelGGL(match_small_kernel<32>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
         else if (p.C == 40) hipLaunchKernelGGL(match_small_kernel<40>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
