@@ -372,8 +372,8 @@ int stem_dw_tiles(int OH, int OW) { return ((OW + SD_TW - 1) / SD_TW) * ((OH + S
 void launch_stem_dw(const StemDwParams& q, hipStream_t s) {
     const int tiles = q.st.B * stem_dw_tiles(q.st.OH, q.st.OW);
     const size_t lds = (size_t)(((3 * SD_PH * SD_PITCH + 3) & ~3) + SD_SH * SD_SW * 32 + 4 * 32 + 9 * 32 + 27 * 32) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    static LdsAttr attr;
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(stem_dw_kernel), lds);
     hipLaunchKernelGGL(stem_dw_kernel, dim3(std::min(tiles, 512)), dim3(256), lds, s, q);
 }
 
