@@ -68,7 +68,9 @@ struct MbImgParams {
 // feeding two MFMA chains, one workgroup of 512 threads per CU whose depthwise phase is one pass of all threads: 0.627 against 0.612 ms
 // for blocks 11-15 at batch 32, the overlap of two out-of-phase workgroups is worth as much as the halved input traffic; the two halves of a
 // tile as a ring - a half requested for the next tile as soon as it is read, `vmcnt(other half)` waits - 2.361 against 2.353 ms over the 29
-// launches: spreading the requests changes nothing.)
+// launches: spreading the requests changes nothing; the items of the strip layers dealt round robin inside an XCD, so that the nine chunks
+// of a strip - which read the same 150 KB of input - run on nine workgroups at once instead of one after the other (FETCH_SIZE of blocks 2 / 3
+// is 9x their input): 0.859 against 0.765 ms for blocks 2-5 - every item then starts with a new strip's zero-fill and tables.)
 template <int K, int S, int KCH, int SK, int TX, int TY, int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mbconv_image_kernel(const MbImgParams q) {
     constexpr int NWV = NT / 64;
