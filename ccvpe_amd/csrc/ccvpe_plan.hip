@@ -45,7 +45,8 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
     int ch = conv_out(H, 3, 2), cw = conv_out(W, 3, 2);
     // stem + the depthwise conv of block 0 in one launch (block 0 has no expand conv; kernels_encoder.hip): the half-resolution 32-channel
     // stem output never reaches HBM.  CCVPE_STEM_DW=0: two launches (read per plan: tests toggle it)
-    const bool stem_dw = !(getenv("CCVPE_STEM_DW") && std::atoi(getenv("CCVPE_STEM_DW")) == 0) && B0[0].e == 1 && B0[0].k == 3 && B0[0].s == 1 && B0[0].cin == 32;
+    const bool stem_dw = !(getenv("CCVPE_STEM_DW") && std::atoi(getenv("CCVPE_STEM_DW")) == 0) && B0[0].e == 1 && B0[0].k == 3 && B0[0].s == 1 && B0[0].cin == 32 &&
+                         (size_t)B * 3 * H * W * sizeof(float) < ((size_t)1 << 31);   // (the kernel addresses its input through one 32-bit buffer descriptor)
     StemParams stem_sp{};
     stem_sp.B = B; stem_sp.H = H; stem_sp.W = W; stem_sp.OH = ch; stem_sp.OW = cw; stem_sp.pad_t = lo; stem_sp.pad_l = lo; stem_sp.circular = circular;
     stem_sp.w = ew.stem_w; stem_sp.bias = ew.stem_b;
