@@ -170,11 +170,11 @@ def main() -> int:
     def traffic_from_profiles(kernel: str):
         """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (bench.py cannot run
         the profiler on itself; the file names its command): 2*FETCH_SIZE + WRITE_SIZE of one representative launch."""
-        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     t = json.load(fh)
-                if t.get("kernel") == kernel:
+                if t.get("kernel") == kernel or t.get("kernel", "").split("_splitk")[0].replace("_tailsplit", "") == kernel:
                     return t["hbm_bytes_per_launch"], t.get("algorithmic_bytes_per_launch"), "profiles/" + name
             except (OSError, ValueError, KeyError):
                 continue
@@ -183,12 +183,13 @@ def main() -> int:
     def cpu_baseline(variant, kw, fov):
         """The oracle (CPU port of the reference graph, proven equal to it in the build container) on the host cores,
         as BASELINE.md section 4 plans it: batch 1 (BASELINE.json configs[0]), warm-up 1, median of 5 under no_grad,
-        3 forwards with autograd recording (as train_VIGOR.py:282 runs it), and one batch-8 forward."""
+        3 forwards with autograd recording (as train_VIGOR.py:282 runs it), batch 8 (warm-up 1, median of 3) and the headline
+        batch 32 (warm-up 1, one timed forward: ~20 s each) - about a minute of CPU work in all."""
         from oracle import ccvpe_oracle as orc   # checker / baseline only - never on the product path
         cores = usable_cores()
         torch.set_num_threads(cores)
         sd = weights.generate_state_dict(variant, 0)
-        g, s = weights.generate_inputs(variant, 8, 0, fov)
+        g, s = weights.generate_inputs(variant, 32, 0, fov)
         g, s = torch.from_numpy(g), torch.from_numpy(s)
         circ, noise = kw.get("circular_padding", False), kw.get("ori_noise")
 
@@ -204,11 +205,15 @@ def main() -> int:
         t1 = timed(lambda: orc.forward(variant, sd, g[:1], s[:1], circ, noise), 5)
         sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v) for k, v in sd.items()}   # parameters, not BN buffers
         tg = timed(lambda: orc.forward(variant, sdg, g[:1], s[:1], circ, noise, grad=True), 3)
-        t8 = timed(lambda: orc.forward(variant, sd, g, s, circ, noise), 1)
+        orc.forward(variant, sd, g[:8], s[:8], circ, noise)   # warm-up (allocator, thread pool at this size)
+        t8 = timed(lambda: orc.forward(variant, sd, g[:8], s[:8], circ, noise), 3)
+        orc.forward(variant, sd, g, s, circ, noise)           # warm-up
+        t32 = timed(lambda: orc.forward(variant, sd, g, s, circ, noise), 1)
         return {"value": 1.0 / t1, "unit": "queries/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
                 "sample": f"batch-1 forwards of the same model (BASELINE.json configs[0]): warm-up 1, median of 5, torch {torch.__version__} CPU fp32, no_grad",
                 "batch1_autograd_on": {"value": 1.0 / tg, "note": "median of 3, autograd recording as in train_VIGOR.py:282"},
-                "batch8": {"value": 8.0 / t8, "note": "one batch-8 forward (a quarter of the headline batch)"}}
+                "batch8": {"value": 8.0 / t8, "note": "batch-8 forwards: warm-up 1, median of 3"},
+                "batch32": {"value": 32.0 / t32, "note": "the headline batch (BASELINE.json configs[1] on the CPU): warm-up 1, one timed forward, no_grad"}}
 
     if args.dry_run:
         rank, local_rank, world = D.init_from_env("gloo")
@@ -389,8 +394,20 @@ def main() -> int:
         total_ms = sum(v[0] for v in groups.values())
         # tiled GEMM / Winograd launches (tag = tile name) - the candidates for the dominant kernel ...
         mfma = {k: v for k, v in groups.items() if k.startswith(("conv_igemm", "conv_bf16x3", "conv_wino", "conv_pw", "conv_proj"))}
-        dom = max(mfma, key=lambda k: mfma[k][0])
-        ms, fl, by, cnt, iss = mfma[dom]
+        # the dominant KERNEL is a template instantiation (= tile name: conv_wino4_16x128 is conv_wino4_kernel<8>, conv_wino4_16x64 is
+        # conv_wino4_kernel<4> in a rocprofv3 trace); its launches may differ in split-K, which only changes the grid: the tile-tag
+        # groups (tile + split) are kept as `sub_groups`
+        def instantiation(tag):
+            return tag.split("_splitk")[0].replace("_tailsplit", "")
+        inst = {}
+        for k, v in mfma.items():
+            gr = inst.setdefault(instantiation(k), [0.0, 0.0, 0.0, 0, 0.0])
+            for i in range(5):
+                gr[i] += v[i]
+        dom = max(inst, key=lambda k: inst[k][0])
+        ms, fl, by, cnt, iss = inst[dom]
+        sub_groups = {k: {"launches_per_step": v[3], "ms_per_step": v[0], "issued_tflops": v[4] / (v[0] * 1e-3) / 1e12,
+                          "frac": v[4] / (v[0] * 1e-3) / 1e12 / peak} for k, v in sorted(mfma.items()) if instantiation(k) == dom}
         # ... and every launch whose arithmetic runs on the matrix cores: + the fused last decoder level (level1_kernel), the fused
         # MBConv fronts (expand GEMM + depthwise) and the MFMA rolling match of the wide levels
         def on_matrix_cores(tag):
@@ -413,6 +430,7 @@ def main() -> int:
             "algorithmic_tflops": fl / (ms * 1e-3) / 1e12,
             "avg_launch_ms": ms / cnt, "issued_flops_per_launch": iss / cnt, "algorithmic_flops_per_launch": fl / cnt,
             "traffic": traffic, "traffic_algorithmic": traffic_alg, "traffic_source": traffic_src,
+            "sub_groups": sub_groups,
             "all_mfma_kernels": {"issued_tflops": all_iss / (all_ms * 1e-3) / 1e12, "frac": all_iss / (all_ms * 1e-3) / 1e12 / peak,
                                  "algorithmic_tflops": all_fl / (all_ms * 1e-3) / 1e12, "share_of_serial_step": all_ms / total_ms},
             "hbm_bound": None if hdom is None else {
@@ -425,7 +443,12 @@ def main() -> int:
             "serial_step_ms": total_ms,
             "end_to_end": {"gflop_per_query": GFLOP_PER_QUERY[args.workload],
                            "algorithmic_tflops": line["value"] / world * GFLOP_PER_QUERY[args.workload] / 1e3,
-                           "frac_of_fp32_mfma_peak": line["value"] / world * GFLOP_PER_QUERY[args.workload] / 1e3 / PEAK_FP32_MFMA_TFLOPS},
+                           "frac_of_fp32_mfma_peak": line["value"] / world * GFLOP_PER_QUERY[args.workload] / 1e3 / PEAK_FP32_MFMA_TFLOPS,
+                           # what the matrix pipe actually executes per query (Winograd tiles issue 1/4 or 4/9 of the direct count, tile
+                           # and K padding included) x the TIMED two-stream rate: the whole step's matrix-pipe utilisation, always <= 1
+                           "issued_gflop_per_query": all_iss / args.batch / 1e9,
+                           "issued_tflops": line["value"] / world * all_iss / args.batch / 1e12,
+                           "issued_frac": line["value"] / world * all_iss / args.batch / 1e12 / peak},
         }
         if args.breakdown:
             print(f"{'launch':48s} {'ms':>9s} {'alg TF/s':>9s} {'iss TF/s':>9s} {'GB/s':>9s}", file=sys.stderr)

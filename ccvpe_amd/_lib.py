@@ -37,6 +37,7 @@ SYMBOLS = [
     ("ccvpe_finalize_weights", C.c_int, [C.c_void_p]),
     ("ccvpe_save_packed", C.c_int, [C.c_void_p, C.c_char_p]),
     ("ccvpe_load_packed", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("ccvpe_pack_switches", C.c_char_p, []),
     ("ccvpe_import_tuning", C.c_int, [C.c_void_p, C.c_char_p]),
     ("ccvpe_export_tuning", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ccvpe_tuning_generation", C.c_int, [C.c_void_p]),

@@ -128,11 +128,26 @@ size_t ccvpe_workspace_bytes(ccvpe_handle h, int32_t batch, int32_t grd_h, int32
 }
 
 // Issue a plan's ops: in order on one stream, or on two streams with event edges for the cross-stream dependencies.
+// First issue of a plan: every tiled launch must run the (tile, split-K) its plan entry names.  launch_conv_igemm falls back to the shape
+// heuristic when a tile cannot serve a launch (a hand-edited or foreign tuning table): legal, but then "same table -> same launches ->
+// same bits" no longer holds, so it is said out loud once per plan.
+static void check_issued_tile(Plan& pl, const Op& op) {
+    const int got = conv_igemm_last_tile();
+    if (!op.tile || (*op.tile & 0xff) == 0 || got == 0) return;
+    const int want = *op.tile, ws = (want >> 8) & 0xff, gs = (got >> 8) & 0xff;
+    if ((want & 0xff) != (got & 0xff) || (ws > 1 ? ws : 1) != (gs > 1 ? gs : 1))
+        std::fprintf(stderr, "ccvpe: launch %s (batch %d) runs %s split %d instead of the planned %s split %d\n", op.name.c_str(), pl.B,
+                     conv_igemm_tile_name(got), gs, conv_igemm_tile_name(want), ws);
+}
+
 static int run_ops(ccvpe_handle h, Plan& pl, const Ctx& base, hipStream_t s0) {
+    const bool check = !pl.tiles_checked;
+    pl.tiles_checked = true;
+    if (check) (void)conv_igemm_last_tile();
     if (!pl.two_streams || h->serial_issue) {
         Ctx c = base;
         c.stream = s0;
-        for (auto& op : pl.ops) op.fn(c);
+        for (auto& op : pl.ops) { op.fn(c); if (check) check_issued_tile(pl, op); }
         base.conv_errors += c.conv_errors;
         return 0;
     }
@@ -169,6 +184,7 @@ static int run_ops(ccvpe_handle h, Plan& pl, const Ctx& base, hipStream_t s0) {
         };
         if (snap) { if (int r = take_snap(0)) return r; }
         op.fn(c[op.stream]);
+        if (check) check_issued_tile(pl, op);
         if (snap) { if (int r = take_snap(1)) return r; }
         if (op.signal) HIPCHK(hipEventRecord(pl.events[i], st[op.stream]));
     }

@@ -216,6 +216,7 @@ struct Plan {
     Tensor tune_cache;            // encode plans: stand-in for the caller's cache while the plan is being autotuned
     hipGraphExec_t exec = nullptr;
     int runs = 0;
+    bool tiles_checked = false;   // the first issue compared every tiled launch with its plan entry (ccvpe_api.hip: check_issued_tile)
     // Two-stream execution: the aerial encoder and the orientation decoder are issued on a second stream, so the
     // ramp-up / drain of the ~330 short kernels of one chain is filled by the other chain.  Dependencies come from
     // the ops' tensor lists (any two ops that touch the same tensor stay ordered), and a two-stream plan gives every

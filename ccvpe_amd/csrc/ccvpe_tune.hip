@@ -9,14 +9,17 @@
 // name, GEMM shape and which kernel families may serve it - so the decoder launches of a full forward, of a cached-aerial
 // forward and of a debug plan share their entries, and a switch that changes a layer's shape or eligibility gives another
 // key.  Tiles are stored by NAME: a table survives library builds that renumber or add tiles.
+// Keys are at most TUNING_KEY_MAX characters (the text form reads them with a bounded %s); a longer one - an op name nobody
+// has written yet - yields the empty key, which is never stored or looked up: such a launch is measured in every process.
+static constexpr size_t TUNING_KEY_MAX = 255;
 std::string tuning_key(ccvpe_handle_s* h, const Plan& pl, const Op& op) {
-    char buf[256];
-    std::snprintf(buf, sizeof(buf), "v%d_r%d_c%d_p%d_b%d|%s|%dx%dx%d|%d%d%d%d", h->cfg.variant, h->rolls[1], h->cfg.circular_padding,
-                  h->cfg.reserved[0], pl.B, op.name.c_str(), op.gemm_m, op.gemm_n, op.gemm_kpad, op.wino_ok ? 1 : 0, op.wino4_ok ? 1 : 0,
-                  op.is_pw ? 1 : 0, op.bf16x3_only ? 1 : 0);
-    if (op.wino4x_ok) std::strcat(buf, "x");
-    if (op.proj_ok) std::strcat(buf, "p");
-    return buf;
+    char head[64], tail[64];
+    std::snprintf(head, sizeof(head), "v%d_r%d_c%d_p%d_b%d|", h->cfg.variant, h->rolls[1], h->cfg.circular_padding, h->cfg.reserved[0], pl.B);
+    std::snprintf(tail, sizeof(tail), "|%dx%dx%d|%d%d%d%d%s%s", op.gemm_m, op.gemm_n, op.gemm_kpad, op.wino_ok ? 1 : 0, op.wino4_ok ? 1 : 0,
+                  op.is_pw ? 1 : 0, op.bf16x3_only ? 1 : 0, op.wino4x_ok ? "x" : "", op.proj_ok ? "p" : "");
+    std::string key = std::string(head) + op.name + tail;
+    if (key.size() > TUNING_KEY_MAX || key.find_first_of(" \t\n") != std::string::npos) return std::string();
+    return key;
 }
 
 static int tile_by_name(const std::string& name) {
@@ -35,7 +38,8 @@ static int apply_tuning(ccvpe_handle_s* h, Plan& pl, std::vector<bool>& known) {
         if (!op.tile) continue;
         int t = -1, split = 0;
         if (h->tuning_lookup) {
-            auto e = h->tuning.find(tuning_key(h, pl, op));
+            const std::string key = tuning_key(h, pl, op);
+            auto e = key.empty() ? h->tuning.end() : h->tuning.find(key);
             if (e != h->tuning.end()) { t = tile_by_name(e->second.first); split = e->second.second; }
         }
         if (t < 0) { ++missing; continue; }
@@ -49,27 +53,34 @@ static void record_tuning(ccvpe_handle_s* h, const Plan& pl) {
     for (const auto& op : pl.ops) {
         if (!op.tile) continue;
         const int cfg = *op.tile;
-        h->tuning[tuning_key(h, pl, op)] = {(cfg & 0xff) ? conv_igemm_tile_name(cfg & 0xff) : "auto", (cfg >> 8) & 0xff};
+        const std::string key = tuning_key(h, pl, op);
+        if (!key.empty()) h->tuning[key] = {(cfg & 0xff) ? conv_igemm_tile_name(cfg & 0xff) : "auto", (cfg >> 8) & 0xff};
     }
 }
 
 extern "C" {
 
-/* text form: one "op <key> <tile name> <split code>" line per launch; '#' lines are comments */
+/* text form: one "op <key> <tile name> <split code>" line per launch; '#' lines are comments.  All or nothing: the text is parsed
+   into a temporary table that replaces / extends the handle's entries only when every line was understood, so a failing call leaves
+   the handle exactly as it was.  A tile name this build does not know is kept (a table survives builds that add or drop tiles): the
+   launch it names is then measured like an unknown one. */
 int ccvpe_import_tuning(ccvpe_handle h, const char* text) {
     if (!h || !text) return ccvpe_fail(CCVPE_EINVAL, "null argument");
-    int n = 0;
+    std::map<std::string, std::pair<std::string, int>> parsed;
     const char* p = text;
     while (*p) {
         const char* e = std::strchr(p, '\n');
         const std::string line(p, e ? (size_t)(e - p) : std::strlen(p));
         p = e ? e + 1 : p + line.size();
-        char a[256], b[256];
+        char a[TUNING_KEY_MAX + 2], b[66];
         int split = 0;
-        if (std::sscanf(line.c_str(), "op %255s %255s %d", a, b, &split) == 3 && split >= 0 && split <= 255) { h->tuning[a] = {b, split}; ++n; }
-        else if (!line.empty() && line[0] != '#') return ccvpe_fail(CCVPE_EINVAL, "tuning table: cannot parse '%s'", line.c_str());
+        // one more character than the limits allow is read, so an over-long field is seen (and refused) instead of being cut
+        if (std::sscanf(line.c_str(), "op %256s %65s %d", a, b, &split) == 3 && std::strlen(a) <= TUNING_KEY_MAX && std::strlen(b) <= 64 && split >= 0 && split <= 255)
+            parsed[a] = {b, split};
+        else if (!line.empty() && line[0] != '#') return ccvpe_fail(CCVPE_EINVAL, "tuning table: cannot parse '%.200s'", line.c_str());
     }
-    return n;
+    for (auto& kv : parsed) h->tuning[kv.first] = kv.second;
+    return (int)parsed.size();
 }
 
 int ccvpe_export_tuning(ccvpe_handle h, char* buf, size_t capacity, size_t* needed) {
@@ -204,8 +215,13 @@ int get_plan(ccvpe_handle_s* h, int B, int gh, int gw, Plan** out, int mode) {
     if (apply_tuning(h, *pl, known) > 0 && h->autotune) {
         int rc2 = autotune_plan(h, *pl, &known);
         if (rc2) return rc2;
-        record_tuning(h, *pl);
-        h->tuned_plans++;
+        // choices made under a candidate-filter switch (CCVPE_TUNE_PREFER_*, CCVPE_NO_PW, CCVPE_TUNE_SPLITK ...) stay in this plan:
+        // the key does not name the switch, so recording them would hand the filtered tiles to every later default process
+        // through ccvpe_export_tuning / the user cache
+        if (h->tuning_lookup) {
+            record_tuning(h, *pl);
+            h->tuned_plans++;
+        }
     }
     *out = pl.get();
     h->plans.push_back(std::move(pl));

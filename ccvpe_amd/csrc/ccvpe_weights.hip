@@ -69,6 +69,17 @@ static int upload(ccvpe_handle_s* h, const std::vector<float>& v, float** out) {
     return 0;
 }
 
+// Environment switches the packer branches on: ONE list, read by pack_conv's callers' cache key (ccvpe_pack_switches) - a packed-weight
+// file written under one setting must never be loaded under another (ccvpe_load_packed restores every descriptor from the file).
+static const char* const PACK_SWITCHES[] = {"CCVPE_NO_PROJ", "CCVPE_WINO4_MIN_N", "CCVPE_NO_WINO4", "CCVPE_NO_WINO4X"};
+extern "C" const char* ccvpe_pack_switches(void) {
+    static thread_local std::string s;
+    s.clear();
+    for (const char* k : PACK_SWITCHES)
+        if (const char* v = getenv(k)) s += std::string(k) + "=" + v + ";";
+    return s.c_str();
+}
+
 // Generic packer: rows n < N, k = tap*cinp + cmap(c).  `get(n, tap, c)` returns the (already scaled) weight.
 int pack_conv(ccvpe_handle_s* h, PackedConv& pc, int N, int taps, int cin, int cinp, const std::vector<int>& cmap,
                      const std::function<float(int, int, int)>& get, const std::vector<float>& bias, int KH, int KW) {

@@ -215,9 +215,9 @@ class _CVMBase(nn.Module):
             hsh.update(key.encode())
             hsh.update(t.detach().cpu().contiguous().numpy().tobytes())
         # switches that change what the packer emits are part of the key, and so is the library actually loaded
-        sw = "".join(f"{k}={os.environ[k]};" for k in ("CCVPE_NO_WINO4", "CCVPE_WINO4_MIN_N", "CCVPE_WINOGRAD") if k in os.environ)
+        sw = _lib.load().ccvpe_pack_switches() or b""   # the library's own list: whatever its packer branches on
         if sw:
-            hsh.update(sw.encode())
+            hsh.update(sw)
         tag = f"{self._variant}-{self._precision}-{int(self.circular_padding)}-{_lib.library_digest()[:16]}-{hsh.hexdigest()[:32]}"
         return os.path.join(self._weight_cache, tag + ".ccvpepack")
 

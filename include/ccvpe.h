@@ -118,6 +118,10 @@ int ccvpe_finalize_weights(ccvpe_handle h);
  * CCVPE_EINVAL if the file is missing, truncated, or was packed for another variant / precision / library build. */
 int ccvpe_save_packed(ccvpe_handle h, const char* path);
 int ccvpe_load_packed(ccvpe_handle h, const char* path);
+/* The environment switches that change what the packer emits, as "NAME=value;" pairs in a fixed order ("" when none is set;
+ * thread-local storage, valid until the thread's next call): part of the caller's cache key, so a file packed under one setting
+ * is never loaded under another.  No reference counterpart. */
+const char* ccvpe_pack_switches(void);
 
 /* Tuning table.  The first forward of a new (batch, ground size) measures every tiled launch of its plan with each candidate
  * kernel tile and keeps the fastest (1-2 s at batch 32); the choices are the only thing about a forward that can differ between

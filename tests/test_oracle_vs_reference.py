@@ -11,7 +11,9 @@ pytestmark = pytest.mark.skipif(not rh.available(), reason="reference tree not p
 
 
 @pytest.mark.parametrize("variant,circ,noise,fov", [
-    ("vigor_ori_prior", True, 36.0, 360.0),
+    ("vigor_ori_prior", True, 36.0, 360.0),      # all four model classes of the reference (models.py:49, 346, 655, 954)
+    ("vigor", True, None, 360.0),
+    ("kitti", False, None, 360.0),
     ("oxford", False, None, 360.0),
 ])
 def test_full_tensor_agreement(variant, circ, noise, fov):
@@ -20,15 +22,25 @@ def test_full_tensor_agreement(variant, circ, noise, fov):
     grd, sat = weights.generate_inputs(variant, 1, 5, fov)
     grd, sat = torch.from_numpy(grd), torch.from_numpy(sat)
     net = rh.build(variant, sd, circ, noise)
+    raw = {}
+    hook = net.conv1_ori.register_forward_hook(lambda _m, _i, out: raw.__setitem__("ref", out.detach()))   # models.py:648-649, before F.normalize
     with torch.no_grad():
         ref = net(grd, sat)
-    got = orc.forward(variant, sd, grd, sat, circ, noise)
+    hook.remove()
+    taps = {}
+    got = orc.forward(variant, sd, grd, sat, circ, noise, taps)
     assert len(ref) == len(got) == 9
     for i, (a, b) in enumerate(zip(ref, got)):
         assert a.shape == b.shape
         if i == 2:
-            continue   # orientation checked through its magnitude-weighted form in test_oracle_golden
+            continue
         assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item()
+    # orientation: the un-normalised map in full, and the unit field weighted by the un-normalised magnitude
+    # (F.normalize is ill-conditioned where the raw vector is ~0)
+    assert (raw["ref"] - taps["ori_level1"]).abs().max().item() <= 2e-5 * raw["ref"].abs().max().item()
+    mag = raw["ref"].double().norm(dim=1, keepdim=True)
+    err = ((ref[2].double() - got[2].double()).abs() * mag).max().item()
+    assert err <= 2e-5 * mag.max().item()
 
 
 def test_reference_state_dict_keys_match_spec():

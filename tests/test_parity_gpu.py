@@ -252,6 +252,9 @@ def test_pointwise_persistent_tiles_everywhere_match_golden(name, monkeypatch):
     g, s = inputs(cfg)
     worst = check_against_fixture(fx, m(g, s), RTOL)
     assert worst <= CONTRACT_RTOL
+    # choices measured under a candidate filter stay in the handle's plans: nothing is recorded, exported or written to the shared cache
+    from ccvpe_amd import _lib
+    assert _lib.load().ccvpe_tuning_generation(m._handle) == 0
 
 
 @pytest.mark.parametrize("name,batch", [("vigor_prior180_circ", 1), ("kitti", 1), ("oxford", 3)])

@@ -37,6 +37,13 @@ def build(variant, kw, precision):
     return m.to("cuda").eval()
 
 
+def device_string():
+    """Marketing name when the driver knows one ("AMD Radeon Graphics" on unnamed engineering boards), always with the ISA and CU count."""
+    pr = torch.cuda.get_device_properties(0)
+    arch = getattr(pr, "gcnArchName", "").split(":")[0]
+    return f"{pr.name} ({arch}, {pr.multi_processor_count} CUs, {pr.total_memory / 2**30:.0f} GiB)"
+
+
 def main():
     out = sys.argv[1]
     table = {}
@@ -59,7 +66,7 @@ def main():
             del m
             torch.cuda.empty_cache()
     with open(out, "w") as fh:
-        fh.write("# tuning table of ccvpe_amd (see ccvpe_amd/tuning.py); measured by tools/make_tuning_table.py on " + torch.cuda.get_device_name(0) + "\n")
+        fh.write("# tuning table of ccvpe_amd (see ccvpe_amd/tuning.py); measured by tools/make_tuning_table.py on " + device_string() + "\n")
         fh.write(tuning.render(table))
     print(len(table), "launches ->", out)
 
