@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libccvpe_hip.so")
 STAMP = os.path.join(CSRC, ".libccvpe_hip.stamp")
 SOURCES = ["ccvpe_api.hip", "ccvpe_weights.hip", "ccvpe_plan.hip", "ccvpe_tune.hip", "kernels_igemm.hip", "kernels_igemm_bf16x3.hip", "kernels_wino.hip", "kernels_wino4.hip", "kernels_wino4p.hip", "kernels_wino4x.hip", "kernels_encoder.hip", "kernels_match.hip", "kernels_tail.hip", "kernels_level1.hip", "kernels_mbconv.hip", "kernels_preproc.hip", "kernels_pw.hip", "kernels_proj.hip", "kernels_mbimg.hip"]
-HEADERS = ["kernels.h", "igemm_common.h", "ccvpe_internal.h", os.path.join("..", "..", "include", "ccvpe.h")]
+HEADERS = ["kernels.h", "ticket.h", "igemm_common.h", "ccvpe_internal.h", os.path.join("..", "..", "include", "ccvpe.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 # Per-file flags.  kernels_match.hip: hipcc's SLP vectoriser fuses the dot-product and norm accumulators of match_kernel
 # into v_pk_fma_f32 ... op_sel:[0,1,0]; on gfx950 a packed fp32 instruction whose LOW result takes the HIGH half of src1

@@ -232,6 +232,7 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
         Ctx c;
         c.cache_in = cache;
         c.arena = h->arena; c.off = &pl->off; c.stream = stream;
+        c.tickets = pl->tickets;
         pl->set_scratch(c, 0);
         c.grd = grd + (size_t)done * 3 * gh * gw;
         c.sat = sat ? sat + (size_t)done * 3 * CCVPE_SAT_HW * CCVPE_SAT_HW : nullptr;
@@ -454,6 +455,7 @@ int ccvpe_encode_aerial(ccvpe_handle h, const float* sat, int32_t batch, void* c
     if (rc) return rc;
     Ctx c;
     c.arena = h->arena; c.off = &pl->off; c.stream = (hipStream_t)stream;
+    c.tickets = pl->tickets;
     c.splitk_scratch = c.ptr(pl->scratch); c.splitk_floats = Plan::SPLITK_FLOATS;
     c.sat = sat; c.cache_out = (float*)cache;
     for (auto& op : pl->ops) op.fn(c);

@@ -160,6 +160,7 @@ struct Ctx {
     size_t splitk_floats = 0;
     float* wino_v = nullptr;           // pre-transformed input of the split Winograd form (kernels_wino4p.hip), per stream
     size_t wino_v_floats = 0;
+    unsigned* tickets = nullptr;       // the plan's last-arriver counters (ticket.h); every launch that draws tickets owns a range
     const float* cache_in = nullptr;   // aerial cache consumed by a "cached" plan
     float* cache_out = nullptr;        // aerial cache produced by an "encode" plan
     float* ptr(const Tensor& t) const { return arena + (*off)[t.id]; }
@@ -216,6 +217,11 @@ struct Plan {
     Tensor tune_cache;            // encode plans: stand-in for the caller's cache while the plan is being autotuned
     hipGraphExec_t exec = nullptr;
     int runs = 0;
+    // last-arriver tickets (ticket.h): one device allocation per plan, outside the arena (the autotuner fills the arena with random
+    // numbers, and plans share it), zeroed once when the plan is built - every kernel leaves its counters at zero
+    size_t ticket_words = 0;
+    unsigned* tickets = nullptr;
+    size_t alloc_tickets(size_t n) { const size_t o = ticket_words; ticket_words += (n + 15) & ~(size_t)15; return o; }
     bool tiles_checked = false;   // the first issue compared every tiled launch with its plan entry (ccvpe_api.hip: check_issued_tile)
     // Two-stream execution: the aerial encoder and the orientation decoder are issued on a second stream, so the
     // ramp-up / drain of the ~330 short kernels of one chain is filled by the other chain.  Dependencies come from
@@ -228,6 +234,7 @@ struct Plan {
     ~Plan() {
         if (exec) (void)hipGraphExecDestroy(exec);
         for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e);
+        if (tickets) (void)hipFree(tickets);
     }
     void schedule() {
         if (!two_streams) return;

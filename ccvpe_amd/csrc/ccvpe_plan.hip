@@ -79,20 +79,50 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
                            (h->fuse_mbconv == 2 || (h->fuse_mbconv == 1 && mbconv_front_profitable(b.k))));
         Tensor d = pl.alloc(B, oh, ow, mid);
         const bool with_stem = stem_dw && i == 0;
-        const int S = with_stem ? stem_dw_tiles(oh, ow) : image ? mbconv_image_strips(mp) : fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid, b.k, b.s);
+        // Squeeze-excite by ticket (round 4, ticket.h; model.py:113-118): the front kernel's last-arriving workgroup of a sample reduces the
+        // pooling partials and computes the gates - no launch of its own.  CCVPE_SE_TICKET=0 keeps the separate launches (read per plan:
+        // tests toggle it); kernels that take no ticket (plain depthwise, the workgroup form of the tile kernel) keep them too.
+        const bool ticket_on = !(getenv("CCVPE_SE_TICKET") && std::atoi(getenv("CCVPE_SE_TICKET")) == 0) && mid <= 1152 && bw.sq <= 64;
+        const int trows = !ticket_on ? 0 : with_stem ? stem_dw_tiles(oh, ow) : image ? mbconv_image_ticket_rows(mp) : fused ? mbconv_front_ticket_rows(mp) : 0;
+        const bool ticket = trows > 0;
+        const int S = ticket ? trows : with_stem ? stem_dw_tiles(oh, ow) : image ? mbconv_image_strips(mp) : fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid, b.k, b.s);
         Tensor pool = pl.alloc(B, 1, S, mid);
+        Tensor gate = pl.alloc(B, 1, 1, mid);
+        SeTicket se{};
+        size_t tick_off = 0;
+        if (ticket) {
+            tick_off = pl.alloc_tickets((size_t)B);
+            se.per_sample = with_stem ? S : image ? S * (mid / 16) : S;   // tiles | (strip, 16-channel chunk) items | workgroups of a sample
+            se.S = S; se.C = mid; se.SQ = bw.sq; se.inv_hw = 1.f / (float)(oh * ow);
+            se.w1 = bw.se_w1; se.b1 = bw.se_b1; se.w2 = bw.se_w2; se.b2 = bw.se_b2;
+            se.spec = (long long)B * se.per_sample <= 256 ? 1 : 0;   // latency plans: one workgroup per item, the chip not even filled once
+        }
+        // the image-resident kernel runs the squeeze conv per item (one row of SQ floats each); the others hand over pooling partial rows
+        const bool parts = ticket && image;
+        Tensor sqp = parts ? pl.alloc(B, 1, se.per_sample, bw.sq) : Tensor{};
+        auto fill_se = [=](const Ctx& c) {
+            SeTicket t = se;
+            if (ticket) { t.counter = c.tickets + tick_off; t.pool = c.ptr(pool); t.gate = c.ptr(gate); t.sqpart = parts ? c.ptr(sqp) : nullptr; }
+            return t;
+        };
+        const double se_flops = ticket ? 4.0 * B * mid * bw.sq : 0.0;
         if (with_stem) {
             StemDwParams sd{};
             sd.st = stem_sp; sd.wd = bw.dw_w; sd.bd = bw.dw_b;
-            pl.add(tag + ".stem_b0dw", {d, pool}, [=](const Ctx& c) {
-                StemDwParams q = sd; q.st.in = is_grd ? c.grd : c.sat; q.out = c.ptr(d); q.pool_partial = c.ptr(pool);
+            std::vector<Tensor> uses = {d, pool};
+            if (ticket) uses.push_back(gate);
+            pl.add(tag + ".stem_b0dw", uses, [=](const Ctx& c) {
+                StemDwParams q = sd; q.st.in = is_grd ? c.grd : c.sat; q.out = c.ptr(d); q.pool_partial = c.ptr(pool); q.se = fill_se(c);
                 launch_stem_dw(q, c.stream);
-            }, 2.0 * B * ch * cw * 32 * 27 + 2.0 * B * oh * ow * mid * 9, 4.0 * B * (3.0 * H * W + 32.0 * oh * ow));
+            }, 2.0 * B * ch * cw * 32 * 27 + 2.0 * B * oh * ow * mid * 9 + se_flops, 4.0 * B * (3.0 * H * W + 32.0 * oh * ow));
         } else if (fused) {
-            pl.add(bn + ".expand_dw", {xin, d, pool}, [=](const Ctx& c) {
-                MbFrontParams q = mp; q.x = c.ptr(xin); q.out = c.ptr(d); q.pool = c.ptr(pool);
+            std::vector<Tensor> uses = {xin, d, pool};
+            if (ticket) uses.push_back(gate);
+            if (parts) uses.push_back(sqp);
+            pl.add(bn + ".expand_dw", uses, [=](const Ctx& c) {
+                MbFrontParams q = mp; q.x = c.ptr(xin); q.out = c.ptr(d); q.pool = c.ptr(pool); q.se = fill_se(c);
                 if (image) launch_mbconv_image(q, c.stream); else launch_mbconv_front(q, c.stream);
-            }, 2.0 * B * ch * cw * b.cin * mid + 2.0 * B * oh * ow * mid * b.k * b.k, 4.0 * B * ((double)ch * cw * b.cin + (double)oh * ow * mid));
+            }, 2.0 * B * ch * cw * b.cin * mid + 2.0 * B * oh * ow * mid * b.k * b.k + se_flops, 4.0 * B * ((double)ch * cw * b.cin + (double)oh * ow * mid));
         } else {
         if (b.e != 1) {
             e = pl.alloc(B, ch, cw, mid);
@@ -115,11 +145,10 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
             }, 2.0 * B * oh * ow * mid * b.k * b.k, 4.0 * B * mid * ((double)ch * cw + (double)oh * ow));
         }
         }
-        Tensor gate = pl.alloc(B, 1, 1, mid);
         const int SC = std::max(1, std::min(16, S / 32));
         Tensor pooled = pl.alloc(B, 1, SC, mid);
         Tensor sqt = pl.alloc(B, 1, 1, 64);
-        {
+        if (!ticket) {
             SeParams sp{};
             sp.B = B; sp.S = S; sp.C = mid; sp.SQ = bw.sq; sp.inv_hw = 1.f / (float)(oh * ow); sp.SC = SC;
             sp.w1 = bw.se_w1; sp.b1 = bw.se_b1; sp.w2 = bw.se_w2; sp.b2 = bw.se_b2;

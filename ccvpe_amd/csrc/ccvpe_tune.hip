@@ -104,6 +104,7 @@ int ccvpe_tuning_generation(ccvpe_handle h) { return h ? h->tuned_plans : ccvpe_
 int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
     Ctx c;
     c.arena = h->arena; c.off = &pl.off; c.stream = nullptr;
+    c.tickets = pl.tickets;
     pl.set_scratch(c, 0);
     if (pl.tune_cache.id >= 0) c.cache_out = c.ptr(pl.tune_cache);
     // the candidates run on the null stream inside the shared arena: earlier forwards of this handle may still be in flight
@@ -135,10 +136,12 @@ int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
             if (prefer_pw && op.is_pw && !op.bf16x3_only && !conv_igemm_tile_is_pw(t) && op.gemm_kpad <= 512) continue;
             static const bool prefer_proj = getenv("CCVPE_TUNE_PREFER_PROJ") != nullptr;   // test hook: the deep-K project GEMM wherever it applies
             if (prefer_proj && op.proj_ok && !conv_igemm_tile_is_proj(t)) continue;
+            static const bool prefer_lat = prefer_proj && std::strcmp(getenv("CCVPE_TUNE_PREFER_PROJ"), "lat") == 0;   // ... its latency form only
+            if (prefer_lat && op.proj_ok && op.gemm_m <= 4096 && conv_igemm_tile_proj_rt(t) < 100) continue;
             if (conv_igemm_tile_is_proj(t)) {
-                ConvParams qq{}; qq.M = 1 << 20; qq.N = 16;
-                const int rt = (int)((long long)qq.M / conv_igemm_tile_blocks(qq, t)) / 16;   // the tile's row tiles
+                const int rt = conv_igemm_tile_proj_rt(t);   // row tiles per workgroup; >= 100: the latency form (small M only)
                 if (!op.proj_ok || !conv_proj_has(rt, op.gemm_n) || getenv("CCVPE_NO_PW")) continue;
+                if (rt >= 100 && (op.gemm_m > 4096 || op.gemm_kpad > 1280)) continue;
             } else if (conv_igemm_tile_is_pw(t)) {
                 ConvParams qq{}; qq.M = 16; qq.N = 1 << 20;
                 const int bn = (int)(((long long)qq.N) / conv_igemm_tile_blocks(qq, t));   // the tile's column width
@@ -210,6 +213,10 @@ int get_plan(ccvpe_handle_s* h, int B, int gh, int gw, Plan** out, int mode) {
         if (e != hipSuccess) { h->arena_floats = 0; return ccvpe_fail(CCVPE_ENOMEM, "workspace of %zu bytes: %s", pl->total * sizeof(float), hipGetErrorString(e)); }
         h->arena = (float*)d;
         h->arena_floats = pl->total;
+    }
+    if (pl->ticket_words) {   // the plan's ticket counters: zero now, and every kernel that draws tickets leaves them at zero
+        HIPCHK(hipMalloc((void**)&pl->tickets, pl->ticket_words * sizeof(unsigned)));
+        HIPCHK(hipMemset(pl->tickets, 0, pl->ticket_words * sizeof(unsigned)));
     }
     std::vector<bool> known;
     if (apply_tuning(h, *pl, known) > 0 && h->autotune) {

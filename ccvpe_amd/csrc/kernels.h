@@ -4,6 +4,7 @@
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "ticket.h"
 
 namespace ccvpe {
 
@@ -145,6 +146,8 @@ const PwTile* pw_tile(int i);
 bool conv_pw_supported(const ConvParams& p);
 bool conv_pw_fits(int bn, int kpad);
 bool conv_pw_tile_ok(int i, const ConvParams& p);   // tile i of the family can run this launch
+int conv_pw_tile_proj_rt(int i);                    // row-tile code of a kernels_proj.hip tile (>= 100: its latency form), 0 for the others
+int conv_igemm_tile_proj_rt(int tile);              // the same by tile id
 // deep-K project GEMM (kernels_proj.hip)
 bool conv_proj_supported(const ConvParams& p, int rt);
 void launch_proj(const ConvParams& p, int rt, hipStream_t s);
@@ -177,6 +180,7 @@ struct StemDwParams {
     const float* bd;           // [32]
     float* out;                // NHWC [B,OH,OW,32]: swish(dw(swish(stem)))
     float* pool_partial;       // [B][S][32] partial sums of `out`, S = stem_dw_tiles
+    SeTicket se;               // se.counter != null: the workgroup that finishes a sample last runs its squeeze-excite (ticket.h)
 };
 int stem_dw_tiles(int OH, int OW);   // pooling partial rows per sample
 void launch_stem_dw(const StemDwParams& p, hipStream_t s);
@@ -190,6 +194,7 @@ struct DwParams {
     float* out;                // NHWC [B,OH,OW,C], swish applied
     float* pool_partial;       // [B][S][C] partial sums of `out` for squeeze-excite
     int S;                     // strip lanes per sample
+    SeTicket se;               // se.counter != null: squeeze-excite by the last-arriving workgroup of a sample (ticket.h)
 };
 void launch_depthwise(const DwParams& p, hipStream_t s);
 int depthwise_strip_lanes(int B, int OH, int OW, int C, int k, int stride);
@@ -206,9 +211,15 @@ struct MbFrontParams {
     int k, s, pad_t, pad_l, circular, OH, OW;
     float* out;                // NHWC [B,OH,OW,mid]
     float* pool;               // [B][tiles][mid]
+    SeTicket se;               // se.counter != null: squeeze-excite by the last-arriving workgroup of a sample (ticket.h); the kernels
+                               // that take it are named by the *_ticket_rows functions below (0 = this launch cannot)
 };
 void launch_mbconv_front(const MbFrontParams& p, hipStream_t s);
 int mbconv_front_tiles(int k, int s, int OH, int OW);
+// pooling partial rows per sample when the launch runs with a ticket (the wave-local form then pre-reduces four tiles per workgroup);
+// 0 = the kernel launch_mbconv_front / launch_mbconv_image would pick for these parameters does not take a ticket
+int mbconv_front_ticket_rows(const MbFrontParams& p);
+int mbconv_image_ticket_rows(const MbFrontParams& p);
 bool mbconv_front_supported(int k, int s, int cin, int mid);
 bool mbconv_front_profitable(int k);
 // image-resident form (kernels_mbimg.hip): the whole image, or horizontal strips of it, per 16-channel chunk in LDS

@@ -263,8 +263,14 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const StemDwParams q) {
             }
         return a;
     };
-    if ((int)blockIdx.x < tiles) fetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    // A workgroup owns a contiguous run of tiles (round 4; strided before): its tiles belong to one sample, or to two neighbours, so the
+    // squeeze-excite ticket below is drawn once or twice per workgroup instead of once per tile
+    const int t_lo = (int)((long long)tiles * blockIdx.x / gridDim.x), t_hi = (int)((long long)tiles * (blockIdx.x + 1) / gridDim.x);
+    int se_done = 0;
+    unsigned long long se_last = 0;                                   // samples (relative to the first of this run) whose last ticket we drew
+    const int se_b0 = t_lo / tps;
+    if (t_lo < t_hi) fetch(t_lo);
+    for (int tile = t_lo; tile < t_hi; ++tile) {
         const int b = tile / tps;
         const int tr = tile - b * tps;
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const StemDwParams q) {
             *reinterpret_cast<f32x4s*>(st + (r * SD_SW + c) * 32 + cg * 4) = o;
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < tiles) fetch(tile + gridDim.x);    // the patch is free: the next tile's lands under the depthwise phase
+        if (tile + 1 < t_hi) fetch(tile + 1);                         // the patch is free: the next tile's lands under the depthwise phase
         // ---- depthwise 3x3 from the stem tile: 8 outputs of column `col`; per output ky, kx ascending as in depthwise_kernel ----
         f32x4s pool = {0.f, 0.f, 0.f, 0.f};
         {
@@ -363,7 +369,21 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const StemDwParams q) {
             for (int e = 0; e < 4; ++e) pool[e] += __shfl_xor(pool[e], off);
         if (lane < 8) *reinterpret_cast<f32x4s*>(red + wave * 32 + lane * 4) = pool;
         __syncthreads();
-        if (tid < 32) q.pool_partial[((size_t)b * tps + tr) * 32 + tid] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+        if (tid < 32) st_sc1(q.pool_partial + ((size_t)b * tps + tr) * 32 + tid, red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]);
+        // squeeze-excite by ticket (ticket.h): the workgroup that completes a sample's tps tiles computes its gates; the stem tile `st`
+        // is free here (the next tile's stem phase starts behind a barrier), the patch is not (its DMA is in flight)
+        ++se_done;
+        if (q.se.counter != nullptr && (tile + 1 == t_hi || (tile + 1) / tps != b)) {
+            if (ticket_arrive(q.se.counter + b, (unsigned)se_done, (unsigned)q.se.per_sample, reinterpret_cast<unsigned*>(st + SE_SCR_FLAG)))
+                se_last |= 1ull << (b - se_b0);                       // computed behind the loop (ticket.h)
+            se_done = 0;
+        }
+    }
+    while (se_last) {
+        const int k = __builtin_ctzll(se_last);
+        se_last &= se_last - 1;
+        se_finish<256>(q.se, se_b0 + k, st);
+        __syncthreads();
     }
 }
 

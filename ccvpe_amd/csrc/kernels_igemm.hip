@@ -345,6 +345,7 @@ bool conv_igemm_tile_is_wino(int tile) { tile &= 0xff; return tile > NTILES + bf
 static int pw_index(int tile) { return (tile & 0xff) - NTILES - bf16x3_num_tiles() - wino_num_tiles() - 1; }
 bool conv_igemm_tile_is_pw(int tile) { const int i = pw_index(tile); return i >= 0 && i < pw_num_tiles(); }
 bool conv_igemm_tile_is_proj(int tile) { return conv_igemm_tile_is_pw(tile) && pw_tile(pw_index(tile))->proj_rt > 0; }
+int conv_igemm_tile_proj_rt(int tile) { return conv_igemm_tile_is_pw(tile) ? conv_pw_tile_proj_rt(pw_index(tile)) : 0; }
 bool conv_igemm_tile_is_wino4(int tile) { return conv_igemm_tile_is_wino(tile) && wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->f == 4; }
 bool conv_igemm_tile_is_wino4p(int tile) { return conv_igemm_tile_is_wino4(tile) && wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->pre; }
 static int wino4x_cfg_of(int tile) { return conv_igemm_tile_is_wino(tile) ? wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->xcfg : -1; }

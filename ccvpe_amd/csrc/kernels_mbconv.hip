@@ -181,8 +181,11 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
 // ---------------------------------------------------------------------------------------------------------------------
 static constexpr int ES2 = 20;        // floats per pixel of the 16-channel E tile (conflict-free epilogue writes and b128 reads)
 
-template <int K, int S, int TW, int TH, int KCH>
-__global__ __launch_bounds__(64, KCH == 1 ? 3 : 2) void mbconv_front_wave_kernel(const MbFrontParams p) {
+// NWG = 1: one wave per workgroup, one pooling partial row per tile (squeeze-excite as its own launches).  NWG = 4 (round 4, the
+// ticket form): four INDEPENDENT waves per workgroup - still no barrier in the tile loop - whose channel sums meet in LDS, so a
+// workgroup leaves ONE partial row and draws ONE squeeze-excite ticket (ticket.h); a sample's last workgroup computes its gates.
+template <int K, int S, int TW, int TH, int KCH, int NWG>
+__global__ __launch_bounds__(64 * NWG, KCH == 1 ? 3 : 2) void mbconv_front_wave_kernel(const MbFrontParams p) {
     constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K;
     constexpr int NIP = IW * IH;
     constexpr int NMT = (NIP + 15) / 16;
@@ -190,11 +193,19 @@ __global__ __launch_bounds__(64, KCH == 1 ? 3 : 2) void mbconv_front_wave_kernel
     constexpr int OPL = NOP / 16;            // outputs per lane slot (2 for 8x4, 4 for 8x8)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int CP = KCH * 16;             // input channels padded to 16
-    float* Es = smem;                        // [NMT * 16][ES2] (rows >= NIP: sink of the last m-tile's padding rows)
+    constexpr int ESZ = NMT * 16 * ES2;      // floats of one wave's E tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* Es = smem + wave * ESZ;           // [NMT * 16][ES2] (rows >= NIP: sink of the last m-tile's padding rows)
+    float* psum = smem + NWG * ESZ;          // NWG > 1: [NWG][mid] channel sums of the workgroup's tiles
 
-    const int lane = threadIdx.x;
     const int tiles_x = (p.OW + TW - 1) / TW;
-    const int tile = blockIdx.x, b = blockIdx.y;
+    const int tiles = tiles_x * ((p.OH + TH - 1) / TH);
+    const int tile = blockIdx.x * NWG + wave, b = blockIdx.y;
+    const bool live = tile < tiles;          // (ragged last workgroup: a wave without a tile contributes zeros)
+    if (NWG > 1 && !live)
+        for (int c = lane; c < p.mid; c += 64) psum[wave * p.mid + c] = 0.f;
+    if (live) {
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
@@ -296,21 +307,50 @@ __global__ __launch_bounds__(64, KCH == 1 ? 3 : 2) void mbconv_front_wave_kernel
         for (int off = 4; off < 64; off <<= 1)
 #pragma unroll
             for (int e = 0; e < 4; ++e) pool[e] += __shfl_xor(pool[e], off);
-        if (slot == 0) *reinterpret_cast<f32x4*>(p.pool + ((size_t)b * gridDim.x + tile) * p.mid + c) = pool;
+        if (slot == 0) {
+            if (NWG > 1) *reinterpret_cast<f32x4*>(psum + wave * p.mid + c) = pool;
+            else *reinterpret_cast<f32x4*>(p.pool + ((size_t)b * gridDim.x + tile) * p.mid + c) = pool;
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the E tile is rewritten by the next chunk's expand (the output stores stay in flight)
         __builtin_amdgcn_wave_barrier();
     }
+    }   // live
+    if constexpr (NWG > 1) {
+        // one partial row per workgroup (waves in wave order: deterministic), then the squeeze-excite ticket; the E tiles are free
+        __syncthreads();
+        for (int c = threadIdx.x; c < p.mid; c += 64 * NWG) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWG; ++w) s += psum[w * p.mid + c];
+            st_sc1(p.pool + ((size_t)b * gridDim.x + blockIdx.x) * p.mid + c, s);
+        }
+        if (p.se.counter != nullptr) {
+            // (the ticket's first barrier also orders the psum reads above before the scratch writes of se_finish)
+            if (ticket_arrive(p.se.counter + b, 1u, (unsigned)p.se.per_sample, reinterpret_cast<unsigned*>(smem + SE_SCR_FLAG)))
+                se_finish<64 * NWG>(p.se, b, smem);
+        }
+    }
 }
+
+static constexpr int WAVE_NWG = 4;   // waves per workgroup of the ticket form
 
 template <int K, int S, int TW, int TH, int KCH>
 static void launch_mb_wave(const MbFrontParams& p, hipStream_t s) {
     constexpr int IW = (TW - 1) * S + K, IH = (TH - 1) * S + K, NIP = IW * IH;
-    const size_t lds = (size_t)((NIP + 15) / 16 * 16) * ES2 * sizeof(float);
-    static LdsAttr attr;
-    auto kern = mbconv_front_wave_kernel<K, S, TW, TH, KCH>;
-    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
+    const size_t esz = (size_t)((NIP + 15) / 16 * 16) * ES2 * sizeof(float);
     const int tiles = ((p.OW + TW - 1) / TW) * ((p.OH + TH - 1) / TH);
-    hipLaunchKernelGGL(kern, dim3(tiles, p.B), dim3(64), lds, s, p);
+    if (p.se.counter != nullptr) {   // ticket form: four waves per workgroup, one pooling partial row each
+        const size_t lds = std::max(WAVE_NWG * esz + (size_t)WAVE_NWG * p.mid * sizeof(float), (size_t)SE_SCRATCH_FLOATS * sizeof(float));
+        static LdsAttr attr4;
+        auto kern = mbconv_front_wave_kernel<K, S, TW, TH, KCH, WAVE_NWG>;
+        ensure_dynamic_lds(attr4, reinterpret_cast<const void*>(kern), lds);
+        hipLaunchKernelGGL(kern, dim3((tiles + WAVE_NWG - 1) / WAVE_NWG, p.B), dim3(64 * WAVE_NWG), lds, s, p);
+        return;
+    }
+    static LdsAttr attr;
+    auto kern = mbconv_front_wave_kernel<K, S, TW, TH, KCH, 1>;
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), esz);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.B), dim3(64), esz, s, p);
 }
 
 template <int K, int S, int TW, int TH>
@@ -345,9 +385,19 @@ bool mbconv_front_supported(int k, int s, int cin, int mid) {
 // by default.
 bool mbconv_front_profitable(int k) { return k == 3; }
 
-void launch_mbconv_front(const MbFrontParams& p, hipStream_t s) {
+static bool wave_form_serves(const MbFrontParams& p) {
     static const bool wave_form = !(getenv("CCVPE_MBCONV_WAVE") && std::atoi(getenv("CCVPE_MBCONV_WAVE")) == 0);   // CCVPE_MBCONV_WAVE=0: workgroup form
-    if (wave_form && p.k == 3 && p.cinp <= 48 && p.cinp % 16 == 0 && p.mid % 16 == 0) {
+    return wave_form && p.k == 3 && p.cinp <= 48 && p.cinp % 16 == 0 && p.mid % 16 == 0;
+}
+
+// only the wave-local form takes a squeeze-excite ticket (four tiles per workgroup share a pooling partial row)
+int mbconv_front_ticket_rows(const MbFrontParams& p) {
+    if (!wave_form_serves(p) || p.mid > 1152) return 0;
+    return (mbconv_front_tiles(p.k, p.s, p.OH, p.OW) + WAVE_NWG - 1) / WAVE_NWG;
+}
+
+void launch_mbconv_front(const MbFrontParams& p, hipStream_t s) {
+    if (wave_form_serves(p)) {
         const int kch = p.cinp / 16;
         if (p.s == 1) { if (kch == 1) launch_mb_wave<3, 1, 8, 8, 1>(p, s); else if (kch == 2) launch_mb_wave<3, 1, 8, 8, 2>(p, s); else launch_mb_wave<3, 1, 8, 8, 3>(p, s); }
         else { if (kch == 1) launch_mb_wave<3, 2, 8, 4, 1>(p, s); else if (kch == 2) launch_mb_wave<3, 2, 8, 4, 2>(p, s); else launch_mb_wave<3, 2, 8, 4, 3>(p, s); }

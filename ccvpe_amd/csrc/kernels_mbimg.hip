@@ -172,6 +172,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
     // requests itself again): its expand weights after the barrier that ends the previous expand phase, its taps / bias and every
     // wave's first m-tile at the end of that phase.
     int unit = -1;
+    int se_done = 0;                                       // items finished since the last ticket (all of one sample)
+    unsigned long long se_last = 0;                        // samples (relative to the first one of this share) whose last ticket we drew
+    const int se_b0 = it_lo / max(p.se.per_sample, 1);
+    const bool se_single = (it_hi - 1) / max(p.se.per_sample, 1) == se_b0;   // this share lies inside one sample
+    const bool se_on = p.se.counter != nullptr;            // per_sample == NST * nchunks items complete a sample
+    const bool sq_lane = se_on && wave == 0 && lane < p.se.SQ;
+    const __amdgpu_buffer_rsrc_t se_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(se_on ? p.se.w1 : p.we), 0, se_on ? (unsigned)((size_t)p.se.SQ * p.mid * 4) : 0u, 0x00020000);
     Unit cur = decode_unit(it_lo / q.nchunks);
     {
         const int ch = it_lo - (it_lo / q.nchunks) * q.nchunks;
@@ -255,6 +262,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
         __syncthreads();                                   // E image, taps and bias of this chunk complete; everybody holds the weights
         CCVPE_MI_STAMP(2);
         CCVPE_MI_DMA_W(chn);                               // lands under the depthwise phase
+        // distributed squeeze (ticket.h): lane j < SQ of wave 0 fetches w1[j][ch0 .. ch0 + 15] (64 bytes) for the end of the item; every
+        // other lane asks for an out-of-range offset (no traffic, no branch around loads)
+        f32x4 sqw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            sqw[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(se_rsrc, sq_lane ? (unsigned)((lane * p.mid + ch0) * 4) : 0x80000000u, e * 16, 0));
 
         // ---- depthwise K x K, stride S, from the E image ----
         const f32x4 bd = *reinterpret_cast<const f32x4*>(bds + dq4 * 4);
@@ -310,14 +323,45 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
         if (lane < 4) *reinterpret_cast<f32x4*>(red + wave * 16 + lane * 4) = pool;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk's weights (this wave's share) have landed
         __syncthreads();                                   // E image free again; wave partials and the weights visible
-        if (tid < 16) {
+        if (wave == 0) {
             float s = 0.f;
+            if (lane < 16) {
 #pragma unroll
-            for (int w = 0; w < NT / 64; ++w) s += red[w * 16 + tid];
-            p.pool[(size_t)unit * p.mid + ch0 + tid] = s;  // [B][NST][mid]: one partial row per strip
+                for (int w = 0; w < NT / 64; ++w) s += red[w * 16 + lane];
+            }
+            if (!se_on) {
+                if (lane < 16) p.pool[(size_t)unit * p.mid + ch0 + lane] = s;   // [B][NST][mid]: one partial row per strip (launch_se reads them)
+            } else {
+                // this item's share of the squeeze conv (model.py:115 is linear in the pooled sums): lane j adds w1[j][ch0 + c] * sum[c]
+                // over the item's 16 channels (sum[c] sits in lane c); one row of SQ floats per item, write-through for the ticket below
+                float a = 0.f;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a = fmaf(sqw[c >> 2][c & 3], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), c)), a);   // (the builtin moves 32 bits: integers by its prototype)
+                if (lane < p.se.SQ) st_sc1(p.se.sqpart + ((size_t)b * p.se.per_sample + (it - b * p.se.per_sample)) * p.se.SQ + lane, a);
+            }
         }
         // (red is rewritten only after the next item's first barrier, which wave 0 reaches after these reads)
+        // ---- squeeze-excite by ticket (ticket.h): this workgroup's items of sample b are done when the next item belongs to another
+        // sample (or there is none); whoever completes the sample's NST x nchunks items computes its gates.  The E image is free here.
+        ++se_done;
+        if (se_on && !se_single && (it + 1 == it_hi || (it + 1) / p.se.per_sample != b)) {
+            if (ticket_arrive(p.se.counter + b, (unsigned)se_done, (unsigned)p.se.per_sample, reinterpret_cast<unsigned*>(Es + SE_SCR_FLAG)))
+                se_last |= 1ull << (b - se_b0);            // the gates of this sample are ours to compute - behind the loop (ticket.h)
+            se_done = 0;
+        }
         CCVPE_MI_STAMP(4);
+    }
+    if (se_on && se_single) {   // all items of one sample: one ticket, drawn here (latency plans: with the excite weights already requested)
+        if (p.se.spec) se_arrive_and_finish_parts_spec<NT>(p.se, se_b0, (unsigned)(it_hi - it_lo), Es);
+        else if (ticket_arrive(p.se.counter + se_b0, (unsigned)(it_hi - it_lo), (unsigned)p.se.per_sample, reinterpret_cast<unsigned*>(Es + SE_SCR_FLAG)))
+            se_finish_parts<NT>(p.se, se_b0, Es);
+    }
+    // squeeze-excite of the samples this workgroup completed (a contiguous share of the item list spans a few samples at most)
+    while (se_last) {
+        const int k = __builtin_ctzll(se_last);
+        se_last &= se_last - 1;
+        se_finish_parts<NT>(p.se, se_b0 + k, Es);
+        __syncthreads();
     }
 #if CCVPE_MI_CLOCK
     if (lane == 0) {
@@ -378,7 +422,11 @@ static bool img_plan(const MbFrontParams& p, ImgPlan& pl) {
         int ro = (p.OH + nst - 1) / nst;
         ro = (ro + pl.ty - 1) / pl.ty * pl.ty;
         const int hk = (kch + 1) / 2;
-        if (2 * img_geometry_ro(p, pl.tx, pl.ty, ro, 4, kch, pl.q) <= cap) { pl.nt = 256; pl.sk = kch; }
+        // latency plans (round 4): when the (sample, strip, chunk) items do not even fill the 256 CUs once, two workgroups per CU buy
+        // nothing - eight waves per item halve its m-tiles per wave, and the squeeze-excite tail of the last arriver has twice the loads in flight
+        const bool few = (long long)p.B * ((p.OH + ro - 1) / ro) * (p.mid / 16) <= 256;
+        if (few && img_geometry_ro(p, pl.tx, pl.ty, ro, 8, kch, pl.q) <= cap) { pl.nt = 512; pl.sk = kch; }
+        else if (2 * img_geometry_ro(p, pl.tx, pl.ty, ro, 4, kch, pl.q) <= cap) { pl.nt = 256; pl.sk = kch; }
         else if (kch > 2 && 2 * img_geometry_ro(p, pl.tx, pl.ty, ro, 4, hk, pl.q) <= cap) { pl.nt = 256; pl.sk = hk; }
         else if (img_geometry_ro(p, pl.tx, pl.ty, ro, 8, kch, pl.q) <= cap) { pl.nt = 512; pl.sk = kch; }
         else if (kch > 2 && img_geometry_ro(p, pl.tx, pl.ty, ro, 8, hk, pl.q) <= cap) { pl.nt = 512; pl.sk = hk; }
@@ -410,6 +458,14 @@ int mbconv_image_strips(const MbFrontParams& p) {
     return (mbconv_image_supported(p) && img_plan(p, pl)) ? pl.q.NST : 0;
 }
 
+// The ticket's scratch is the E image (free between two items): the launch takes a ticket when that image is large enough
+int mbconv_image_ticket_rows(const MbFrontParams& p) {
+    ImgPlan pl;
+    if (!mbconv_image_supported(p) || !img_plan(p, pl)) return 0;
+    if ((pl.q.HPa * pl.q.WPa + 1) * EPS < SE_SCRATCH_PARTS_FLOATS || p.mid > 1152 || p.mid % 4 != 0) return 0;
+    return pl.q.NST;
+}
+
 template <int K, int S, int KCH, int SK, int TX, int TY, int NT>
 static void launch_img(const MbFrontParams& p, const ImgPlan& pl, hipStream_t s) {
     const MbImgParams& q = pl.q;
@@ -423,6 +479,15 @@ static void launch_img(const MbFrontParams& p, const ImgPlan& pl, hipStream_t s)
     if (stamp) { (void)hipStreamSynchronize(s); unsigned long long z[12] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mi_clk), z, sizeof z); }
 #endif
     hipLaunchKernelGGL(kern, dim3(std::min(total, NT == 512 ? 256 : 512)), dim3(NT), pl.lds, s, q);   // persistent: 8 waves per CU either way
+#if CCVPE_SE_CLOCK
+    if (p.se.counter && p.se.spec && p.mid >= 480) {
+        (void)hipStreamSynchronize(s);
+        unsigned long long h[16];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_se_clk), sizeof h);
+        std::fprintf(stderr, "se tail mid %d: drain+barrier %.2f  ticket %.2f  reset+acquire %.2f  barrier %.2f  sums+excite %.2f us\n", p.mid, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01,
+                     (h[3] - h[2]) * 0.01, (h[4] - h[3]) * 0.01, (h[5] - h[4]) * 0.01);
+    }
+#endif
 #if CCVPE_MI_CLOCK
     if (stamp) {
         (void)hipStreamSynchronize(s);

@@ -183,7 +183,12 @@ static const PwTile PW_TILES[] = {
     {16, 16, "conv_proj_r1", launch_proj_rt<1>, 1},
     {32, 16, "conv_proj_r2", launch_proj_rt<2>, 2},
     {64, 16, "conv_proj_r4", launch_proj_rt<4>, 4},
+    // ... and its latency form: one row tile x 1 / 2 / 4 column tiles per workgroup of sixteen waves that split K (batch <= 4)
+    {16, 16, "conv_projl_1", launch_proj_rt<101>, 101},
+    {16, 32, "conv_projl_2", launch_proj_rt<102>, 102},
+    {16, 64, "conv_projl_4", launch_proj_rt<104>, 104},
 };
+int conv_pw_tile_proj_rt(int i) { return i >= 0 && i < (int)(sizeof(PW_TILES) / sizeof(PW_TILES[0])) ? PW_TILES[i].proj_rt : 0; }
 int pw_num_tiles() { return (int)(sizeof(PW_TILES) / sizeof(PW_TILES[0])); }
 const PwTile* pw_tile(int i) { return &PW_TILES[i]; }
 bool conv_pw_tile_ok(int i, const ConvParams& p) {

@@ -287,6 +287,36 @@ def test_deep_k_project_gemm_everywhere_matches_golden(name, batch, monkeypatch)
                 assert (a - b).abs().max().item() <= 1e-4 * max(a.abs().max().item(), 1e-30), gu.OUTPUT_NAMES[i]
 
 
+@pytest.mark.parametrize("name,batch", [("vigor_prior180_circ", 1), ("kitti", 1), ("oxford", 1), ("oxford", 3), ("vigor_prior180_b2", 2)])
+def test_latency_form_project_gemm_matches_golden(name, batch, monkeypatch):
+    """Round 4: conv_proj_lat_kernel (sixteen waves of a workgroup split K, every operand requested up front, partial sums meet in LDS;
+    the batch <= 4 form of the gated project convs of blocks 5-15, model.py:113-122) forced wherever it applies (CCVPE_TUNE_PREFER_PROJ=lat)
+    against the goldens: residual and concat-tap epilogues, Oxford's 40-row maps (ragged row tiles that span samples at batch 3)."""
+    monkeypatch.setenv("CCVPE_TUNE_PREFER_PROJ", "lat")
+    cfg = gu.CONFIGS[name]
+    m = build_model(cfg)
+    if batch == cfg["batch"]:
+        fx = gu.load(name)
+        m.set_debug(True)
+        g, s = inputs(cfg)
+        worst = check_against_fixture(fx, m(g, s), RTOL)
+        assert worst <= CONTRACT_RTOL
+        if name == "vigor_prior180_circ":
+            for tap in ["sat_block4", "sat_block10", "sat_block15"]:
+                gu.compare("tap_" + tap, fx, m.read_tap(tap).numpy(), RTOL)
+    else:
+        g, s = inputs(cfg, batch=batch)
+        out = [t.clone() for t in m(g, s)]
+        monkeypatch.delenv("CCVPE_TUNE_PREFER_PROJ")
+        ref = build_model(cfg)(g, s)
+        mag = raw_ori_magnitude(cfg, g, s)
+        for i, (a, b) in enumerate(zip(ref, out)):
+            if i == 2:
+                assert ori_weighted_error(a, b, mag) <= 1e-4
+            else:
+                assert (a - b).abs().max().item() <= 1e-4 * max(a.abs().max().item(), 1e-30), gu.OUTPUT_NAMES[i]
+
+
 @pytest.mark.parametrize("name", ["vigor_prior180_circ", "kitti", "oxford"])
 def test_image_resident_front_kernel_agrees_with_separate_launches(name, monkeypatch):
     """mbconv_image_kernel (blocks 2-15: expand + depthwise + pooling with the expanded image / strip in LDS) against the same
@@ -324,3 +354,30 @@ def test_fused_stem_and_block0_depthwise_agree_with_separate_launches(name, monk
             assert ori_weighted_error(a, b, mag) <= 1e-4, "ori"
             continue
         assert (a - b).abs().max().item() <= 1e-4 * max(a.abs().max().item(), 1e-30), gu.OUTPUT_NAMES[i]
+
+
+@pytest.mark.parametrize("name,batch", [("vigor_prior180_circ", 3), ("kitti", 2), ("oxford", 5), ("vigor_prior72_fov108", 32)])
+def test_squeeze_excite_ticket_agrees_with_separate_launches(name, batch, monkeypatch):
+    """Round 4 (ticket.h): the squeeze-excite of a block (model.py:113-118) is computed by whichever workgroup of the fused front kernel
+    finishes a sample last - pooling partials handed over write-through, one device-scope ticket per workgroup and sample - against
+    the same blocks with se_squeeze / se_excite as their own launches (CCVPE_SE_TICKET=0).  Batch 32 makes workgroups straddle samples
+    (several tickets per workgroup) and samples finish in any order; three repeats must return the same bits (the combining step reads
+    every partial in a fixed order, whoever arrives last)."""
+    cfg = gu.CONFIGS[name]
+    g, s = inputs(cfg, batch=batch)
+    monkeypatch.setenv("CCVPE_SE_TICKET", "0")
+    ref = [t.clone() for t in build_model(cfg)(g, s)]
+    monkeypatch.delenv("CCVPE_SE_TICKET")
+    m = build_model(cfg)
+    out = [t.clone() for t in m(g, s)]
+    mag = raw_ori_magnitude(cfg, g, s)
+    for i, (a, b) in enumerate(zip(ref, out)):
+        if i == 2:   # ori: weighted by the un-normalised magnitude
+            assert ori_weighted_error(a, b, mag) <= 1e-4, "ori"
+            continue
+        assert (a - b).abs().max().item() <= 1e-4 * max(a.abs().max().item(), 1e-30), gu.OUTPUT_NAMES[i]
+    for _ in range(3):
+        again = m(g, s)
+        torch.cuda.synchronize()
+        for a, b in zip(out, again):
+            assert torch.equal(a, b)

@@ -5,6 +5,8 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "postprocess_kernel" in r["Kernel_Name"]]
+if len(marks) < 12:
+    sys.exit(f"{len(rows)} dispatches, {len(marks)} frames in the trace: run rocprofv3 with --output-format csv on tools/b1_frames.py")
 lo, hi = marks[-12] + 1, marks[-2] + 1          # ten frames near the end
 sel = rows[lo:hi]
 nfr = 10
