@@ -165,7 +165,8 @@ static int run_ops(ccvpe_handle h, Plan& pl, const Ctx& base, hipStream_t s0) {
     const size_t n = pl.ops.size();
     HIPCHK(hipEventRecord(pl.events[n], st[0]));            // fork: the second stream starts after the caller's prior work
     HIPCHK(hipStreamWaitEvent(st[1], pl.events[n], 0));
-    for (size_t i = 0; i < n; ++i) {
+    for (size_t k = 0; k < n; ++k) {
+        const size_t i = pl.issue_order.size() == n ? (size_t)pl.issue_order[k] : k;
         Op& op = pl.ops[i];
         for (int d : op.wait_on) HIPCHK(hipStreamWaitEvent(st[op.stream], pl.events[d], 0));
         if (!h->diag_sync.empty() && op.name.find(h->diag_sync) != std::string::npos) HIPCHK(hipDeviceSynchronize());
@@ -314,6 +315,7 @@ static int run_forward(ccvpe_handle h, const float* grd, int gh, int gw, const f
                 if (tile) {
                     nm += std::string("|") + conv_igemm_tile_name(tile);
                     if ((tile >> 8) == 255) nm += "_tailsplit";
+                    else if ((tile >> 8) > SPLIT_FUSED) nm += "_splitk" + std::to_string((tile >> 8) - SPLIT_FUSED) + "r";   // r: reduces itself
                     else if ((tile >> 8) > 1) nm += "_splitk" + std::to_string(tile >> 8);
                     // FLOPs the launch puts on the matrix pipe: M and N padded to the tile, K to the packed depth;
                     // Winograd F(2x2,3x3): 16 products per 2x2 output tile and channel pair; bf16x3: three MFMAs per product
@@ -527,6 +529,7 @@ int ccvpe_debug_dump_plan(ccvpe_handle h, const char* path) {
         std::fprintf(f, "op %zu %s stream=%d wait=%d signal=%d tile=%s", i, op.name.c_str(), op.stream, op.wait_on.empty() ? -1 : op.wait_on[0], (int)op.signal,
                      op.tile ? conv_igemm_tile_name(*op.tile & 0xff) : "-");
         if (op.tile && (*op.tile >> 8) == 255) std::fprintf(f, "_tailsplit");
+        else if (op.tile && (*op.tile >> 8) > SPLIT_FUSED) std::fprintf(f, "_splitk%dr", (*op.tile >> 8) - SPLIT_FUSED);
         else if (op.tile && (*op.tile >> 8) > 1) std::fprintf(f, "_splitk%d", *op.tile >> 8);
         for (int id : op.uses) std::fprintf(f, " t%d[off=%zu,n=%zu]=%016llx", id, pl->off[id], pl->size[id], sums[id]);
         std::fprintf(f, "\n");
@@ -581,8 +584,16 @@ int ccvpe_op_conv2d(const float* in, int32_t B, int32_t H, int32_t W, int32_t Ci
     ConvParams p = conv_params(pc, in, Cin, B, H, W, OH, OW, stride, pad, pad, act);
     p.dst[0] = {out, Cout, 0}; p.ndst = 1;
     hipStream_t st = (hipStream_t)stream;
-    if (((tile >> 8) & 0xff) > 1) {   // tile word = id | (split-K << 8): give the launch a slab
-        const int sk = (tile >> 8) & 0xff;
+    if (((tile >> 8) & 0xff) > 1) {   // tile word = id | (split-K << 8): give the launch a slab (and ticket counters: 255 and the codes above SPLIT_FUSED reduce themselves)
+        int sk = (tile >> 8) & 0xff;
+        if (sk > SPLIT_FUSED && sk != 255) sk -= SPLIT_FUSED;
+        {
+            void* d = nullptr;
+            if (hipMalloc(&d, CONV_TICKETS * sizeof(unsigned)) != hipSuccess || hipMemset(d, 0, CONV_TICKETS * sizeof(unsigned)) != hipSuccess) { cleanup(); return ccvpe_fail(CCVPE_ENOMEM, "ticket counters"); }
+            tmp.dev_allocs.push_back(d);
+            tmp.dev_alloc_bytes.push_back(CONV_TICKETS * sizeof(unsigned));
+            p.tickets = (unsigned*)d;
+        }
         const size_t fl = (size_t)(sk == 255 ? 8 : sk) * p.M * p.N;   // 255 = F(4x4) tail split: its slab is a fraction of 8 full ones
         void* d = nullptr;
         if (hipMalloc(&d, fl * sizeof(float)) != hipSuccess) { cleanup(); return ccvpe_fail(CCVPE_ENOMEM, "split-K slab"); }

@@ -166,7 +166,9 @@ struct Ctx {
     float* ptr(const Tensor& t) const { return arena + (*off)[t.id]; }
     Dst dst(const Tensor& t, int coff = 0) const { return Dst{ptr(t), t.C, coff, t.split ? 1 : 0, t.numel()}; }
     mutable int conv_errors = 0;   // launches refused by launch_conv_igemm (unsupported geometry)
+    mutable size_t conv_tick_off = 0;   // ticket range of the convolution launch being issued (set by Plan::add_conv's wrapper)
     void launch_conv(ConvParams& p, int cfg) const {
+        p.tickets = tickets ? tickets + conv_tick_off : nullptr;
         p.partial = splitk_scratch;
         p.partial_floats = splitk_floats;
         p.wino4_v = wino_v;
@@ -231,6 +233,7 @@ struct Plan {
     Tensor scratch2;              // split-K slab scratch of the second stream
     Tensor vscratch, vscratch2;   // V = B^T d B of the split Winograd F(4x4) form, one per stream (whole-plan lifetime)
     std::vector<hipEvent_t> events;   // one per signalling op + fork + join, created on first use
+    std::vector<int> issue_order;     // two-stream plans: the order the launches are handed to the two streams (schedule())
     ~Plan() {
         if (exec) (void)hipGraphExecDestroy(exec);
         for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e);
@@ -255,6 +258,37 @@ struct Plan {
             }
             if (dep >= 0) { ops[i].wait_on.push_back(dep); ops[dep].signal = true; }
             for (int id : ops[i].uses) last_use[id] = i;
+        }
+        // Issue order (round 4).  In plan order every launch of the ground encoder is issued before the first launch of the aerial encoder:
+        // the host (eagerly: ~3-4 us per launch; a replayed hipGraph submits its nodes in creation order just the same) feeds the second
+        // stream only after ~60 launches of the first, and at batch 1 - where the GPU finishes a launch in 5-20 us - the aerial chain, the
+        // one the decoders wait for, started ~450 us late (rocprofv3 timeline of a replayed frame).  The launches are therefore issued
+        // interleaved: always the stream that is behind (by the number of launches issued), never ahead of a cross-stream dependency.
+        // Any interleaving that keeps each stream's own order and issues a producer before its cross-stream consumer is valid: the
+        // streams' memory pools are recycled in stream order, cross-stream tensors keep private memory (assign()).
+        issue_order.clear();
+        {
+            std::vector<int> q[2];
+            for (int i = 0; i < (int)ops.size(); ++i) q[ops[i].stream].push_back(i);
+            size_t p[2] = {0, 0};
+            std::vector<bool> issued(ops.size(), false);
+            static const bool plan_order = getenv("CCVPE_ISSUE_ORDER") && std::atoi(getenv("CCVPE_ISSUE_ORDER")) == 0;   // A/B switch: plan order
+            while (!plan_order && (p[0] < q[0].size() || p[1] < q[1].size())) {
+                auto ready = [&](int s) {
+                    if (p[s] >= q[s].size()) return false;
+                    for (int d : ops[q[s][p[s]]].wait_on) if (!issued[d]) return false;
+                    return true;
+                };
+                const bool r0 = ready(0), r1 = ready(1);
+                int s;
+                if (r0 && r1) s = (p[1] * q[0].size() < p[0] * q[1].size()) ? 1 : 0;   // the stream that has issued the smaller share of its launches
+                else if (r0 || r1) s = r0 ? 0 : 1;
+                else { issue_order.clear(); break; }                                        // (cannot happen: the dependency graph is acyclic)
+                const int i = q[s][p[s]++];
+                issued[i] = true;
+                issue_order.push_back(i);
+            }
+            if (issue_order.size() != ops.size()) { issue_order.resize(ops.size()); for (int i = 0; i < (int)ops.size(); ++i) issue_order[i] = i; }
         }
         if (getenv("CCVPE_LOG_SCHEDULE"))
             for (int i = 0; i < (int)ops.size(); ++i) {
@@ -293,7 +327,8 @@ struct Plan {
     void add_conv(const std::string& name, std::vector<Tensor> uses, int gemm_m, int gemm_n, int gemm_kpad,
                   std::function<void(const Ctx&, int)> fn, double flops, double bytes) {
         auto tp = std::make_shared<int>(TILE_AUTO);
-        add(name, std::move(uses), [fn, tp](const Ctx& c) { fn(c, *tp); }, flops, bytes);
+        const size_t toff = alloc_tickets(CONV_TICKETS);   // counters of a self-reducing split-K launch (ticket.h)
+        add(name, std::move(uses), [fn, tp, toff](const Ctx& c) { c.conv_tick_off = toff; fn(c, *tp); }, flops, bytes);
         ops.back().tile = tp;
         ops.back().gemm_m = gemm_m;
         ops.back().gemm_n = gemm_n;
@@ -371,7 +406,7 @@ struct ccvpe_handle_s {
     // CCVPE_WINOGRAD=0 keeps the decoder 3x3 layers on the implicit GEMM.  The Winograd kernels serve fp32 plans only: bf16x3 plans keep the
     // decoder tensors as split bf16 planes, which only the bf16x3 tiles read
     bool wino = true;
-    int graph_mode = -1;          // -1 auto (plans of <= 4 samples replay a hipGraph), 0 never, 1 always
+    int graph_mode = 0;           // 1: plans replay a captured hipGraph (CCVPE_GRAPH=1; opt-in since round 4, see build_plan), 0 eager launches
     hipStream_t capture_stream = nullptr;
     hipStream_t aux_stream = nullptr;   // second stream of two-stream plans
     bool two_streams = true;      // CCVPE_STREAMS=1 issues everything on the caller's stream

@@ -84,12 +84,30 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         // tests toggle it); kernels that take no ticket (plain depthwise, the workgroup form of the tile kernel) keep them too.
         const bool ticket_on = !(getenv("CCVPE_SE_TICKET") && std::atoi(getenv("CCVPE_SE_TICKET")) == 0) && mid <= 1152 && bw.sq <= 64;
         const int trows = !ticket_on ? 0 : with_stem ? stem_dw_tiles(oh, ow) : image ? mbconv_image_ticket_rows(mp) : fused ? mbconv_front_ticket_rows(mp) : 0;
-        const bool ticket = trows > 0;
+        // Opt-in (CCVPE_SE_PROLOGUE=1; measured, not the default): latency plans (batch <= 4, blocks of <= 4096 rows) without a ticket either -
+        // the image-resident front leaves its per-item squeeze rows and the latency-form project GEMM computes the gates in its prologue,
+        // every wave those of its own K slice (kernels_proj.hip).  The front kernel loses its ~10 us combining step (block 12: 24.8 -> 15.5 us)
+        // but the project GEMM gains as much (9.7 -> 20.9 us: rows -> squeezed vector -> gates is the same chain of dependent round trips,
+        // now in front of its MFMAs, and its 128-register waves cannot keep all four kinds of requests in flight at once): 1.41 against
+        // 1.28 ms per batch-1 frame.
+        bool sep = false;
+        if (trows > 0 && image && bw.project.proj != nullptr && h->cfg.reserved[0] == 0 && getenv("CCVPE_SE_PROLOGUE") && std::atoi(getenv("CCVPE_SE_PROLOGUE")) == 1) {
+            ConvParams q = conv_params(bw.project, nullptr, mid, B, oh, ow, oh, ow, 1, 0, 0, ACT_NONE);
+            q.M = B * oh * ow;
+            q.se_rows = reinterpret_cast<const float*>(1); q.se_nrows = trows * (mid / 16); q.se_sq = bw.sq;
+            sep = conv_proj_supported(q, 101);
+        }
+        const bool ticket = trows > 0 && !sep;
         const int S = ticket ? trows : with_stem ? stem_dw_tiles(oh, ow) : image ? mbconv_image_strips(mp) : fused ? mbconv_front_tiles(b.k, b.s, oh, ow) : depthwise_strip_lanes(B, oh, ow, mid, b.k, b.s);
         Tensor pool = pl.alloc(B, 1, S, mid);
         Tensor gate = pl.alloc(B, 1, 1, mid);
         SeTicket se{};
         size_t tick_off = 0;
+        if (sep) {   // rows only: SeTicket::counter stays null, sqpart set (mbconv_image_kernel: no ticket, no combining step)
+            se.per_sample = trows * (mid / 16);
+            se.S = trows; se.C = mid; se.SQ = bw.sq; se.inv_hw = 1.f / (float)(oh * ow);
+            se.w1 = bw.se_w1;
+        }
         if (ticket) {
             tick_off = pl.alloc_tickets((size_t)B);
             se.per_sample = with_stem ? S : image ? S * (mid / 16) : S;   // tiles | (strip, 16-channel chunk) items | workgroups of a sample
@@ -98,11 +116,12 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
             se.spec = (long long)B * se.per_sample <= 256 ? 1 : 0;   // latency plans: one workgroup per item, the chip not even filled once
         }
         // the image-resident kernel runs the squeeze conv per item (one row of SQ floats each); the others hand over pooling partial rows
-        const bool parts = ticket && image;
+        const bool parts = (ticket && image) || sep;
         Tensor sqp = parts ? pl.alloc(B, 1, se.per_sample, bw.sq) : Tensor{};
         auto fill_se = [=](const Ctx& c) {
             SeTicket t = se;
-            if (ticket) { t.counter = c.tickets + tick_off; t.pool = c.ptr(pool); t.gate = c.ptr(gate); t.sqpart = parts ? c.ptr(sqp) : nullptr; }
+            if (ticket) { t.counter = c.tickets + tick_off; t.pool = c.ptr(pool); t.gate = c.ptr(gate); }
+            if (parts) t.sqpart = c.ptr(sqp);
             return t;
         };
         const double se_flops = ticket ? 4.0 * B * mid * bw.sq : 0.0;
@@ -119,6 +138,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
             std::vector<Tensor> uses = {xin, d, pool};
             if (ticket) uses.push_back(gate);
             if (parts) uses.push_back(sqp);
+            (void)sep;
             pl.add(bn + ".expand_dw", uses, [=](const Ctx& c) {
                 MbFrontParams q = mp; q.x = c.ptr(xin); q.out = c.ptr(d); q.pool = c.ptr(pool); q.se = fill_se(c);
                 if (image) launch_mbconv_image(q, c.stream); else launch_mbconv_front(q, c.stream);
@@ -148,7 +168,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         const int SC = std::max(1, std::min(16, S / 32));
         Tensor pooled = pl.alloc(B, 1, SC, mid);
         Tensor sqt = pl.alloc(B, 1, 1, 64);
-        if (!ticket) {
+        if (!ticket && !sep) {
             SeParams sp{};
             sp.B = B; sp.S = S; sp.C = mid; sp.SQ = bw.sq; sp.inv_hw = 1.f / (float)(oh * ow); sp.SC = SC;
             sp.w1 = bw.se_w1; sp.b1 = bw.se_b1; sp.w2 = bw.se_w2; sp.b2 = bw.se_b2;
@@ -163,19 +183,28 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
             const bool skip = (b.s == 1 && b.cin == b.cout);
             TapDst td;
             if (tapdst) for (int t = 0; t < 5; ++t) if (TAP_BLOCK[t] == i) td = tapdst[t];
-            std::vector<Tensor> uses = {d, gate, o};
+            std::vector<Tensor> uses = {d, sep ? sqp : gate, o};
             if (skip) uses.push_back(xin);
             for (int t = 0; t < td.n; ++t) uses.push_back(td.t[t]);
-            pl.add_conv(bn + ".project", uses, B * oh * ow, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
+            const int se_nrows = se.per_sample, se_sq = bw.sq;
+            const float se_inv = se.inv_hw;
+            const float *se_b1 = bw.se_b1, *se_w2 = bw.se_w2, *se_b2 = bw.se_b2;
+            pl.add_conv(bn + (sep ? ".se_project" : ".project"), uses, B * oh * ow, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(d), mid, B, oh, ow, oh, ow, 1, 0, 0, ACT_NONE);
-                p.gate = c.ptr(gate);
+                if (sep) {
+                    p.se_rows = c.ptr(sqp); p.se_nrows = se_nrows; p.se_sq = se_sq; p.se_inv_hw = se_inv; p.se_b1 = se_b1; p.se_w2 = se_w2; p.se_b2 = se_b2;
+                    tile = conv_proj_lat_tile();   // the only kernel that computes the gates itself
+                } else {
+                    p.gate = c.ptr(gate);
+                }
                 if (skip) { p.resid = c.ptr(xin); p.resid_ld = xin.C; }
                 p.dst[0] = {c.ptr(o), o.C, 0}; p.ndst = 1;
                 for (int t = 0; t < td.n; ++t) p.dst[p.ndst++] = c.dst(td.t[t], td.coff[t]);
                 c.launch_conv(p, tile);
-            }, 2.0 * B * oh * ow * mid * b.cout, 4.0 * B * oh * ow * (mid + b.cout * (1 + td.n)));
+            }, 2.0 * B * oh * ow * mid * b.cout + (sep ? 4.0 * B * mid * bw.sq : 0.0), 4.0 * B * oh * ow * (mid + b.cout * (1 + td.n)));
             pl.ops.back().is_pw = true;
             pl.ops.back().proj_ok = pc->proj != nullptr && h->cfg.reserved[0] == 0;
+            if (sep) pl.ops.back().tile.reset();   // not a tuning candidate: one kernel serves it (the launch above names its tile)
         }
         out.tap[i] = o;
         pl.taps[tag + "_block" + std::to_string(i)] = {o, 0, o.C};
@@ -240,7 +269,11 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
         if (v0) pl.vscratch = pl.alloc(1, 1, 1, (int)v0);
         if (pl.two_streams && v1) pl.vscratch2 = pl.alloc(1, 1, 1, (int)v1);
     }
-    pl.use_graph = !cached && (h->graph_mode == 1 || (h->graph_mode < 0 && B <= 4));
+    // hipGraph replay: opt-in since round 4 (CCVPE_GRAPH=1).  Rounds 2-3 replayed plans of <= 4 samples: with ~330 launches per frame the
+    // host could not keep up.  A batch-1 frame is 137 launches now; issued eagerly (interleaved over the two streams, Plan::schedule) the
+    // GPU starts on the first while the host still hands over the rest, and a synchronised frame takes 1.31 ms against 1.44 ms replayed
+    // (the replay's set-up precedes its first kernel); back to back both run at the GPU's pace.
+    pl.use_graph = !cached && h->graph_mode == 1;
     if (pl.use_graph) {
         pl.io_grd = pl.alloc(B, 3, gh, gw);
         pl.io_sat = pl.alloc(B, 3, CCVPE_SAT_HW, CCVPE_SAT_HW);
@@ -318,6 +351,8 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
             p.dst[0] = {c.ptr(ghead), ntot, 0}; p.ndst = 1;
             c.launch_conv(p, tile);
         }, 2.0 * B * fh * fw * 1280 * ntot, 4.0 * B * fh * fw * (1280 + ntot));
+        pl.ops.back().is_pw = true;
+        pl.ops.back().proj_ok = pc->proj != nullptr && h->cfg.reserved[0] == 0;
         GrdDescParams gp{};
         gp.B = B; gp.Hf = fh; gp.Wf = fw; gp.Ntot = ntot; gp.nlev = 6; gp.Ltot = ltot;
         for (int k = 0; k < 6; ++k) { gp.c[k] = vs.head_ch[k]; gp.off[k] = hoff[k]; gp.wh[k] = h->grd_wh[k]; gp.b2[k] = h->grd_b2[k]; gp.loff[k] = loff[k]; }
@@ -345,6 +380,7 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
             p.dst[0] = {c.ptr(dmap), D, 0}; p.ndst = 1;
             c.launch_conv(p, tile);
         }, 2.0 * B * 64 * 5120.0 * D, 4.0 * (B * 256 * 1280.0 + 5120.0 * D));
+        pl.ops.back().proj_ok = pc->proj != nullptr && h->cfg.reserved[0] == 0;   // (k2s2: the latency form of kernels_proj.hip only)
         pl.taps["sat_descriptor_map"] = {dmap, 0, D};
     }
 
@@ -362,6 +398,7 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
                 c.launch_conv(p, tile);
             }, 2.0 * B * hin * hin * (double)l.din * 4 * l.dout, 4.0 * B * hin * hin * ((double)din.C + 4.0 * l.dout));
             pl.ops.back().is_pw = !din.split;
+            pl.ops.back().proj_ok = pc->proj != nullptr && !din.split && h->cfg.reserved[0] == 0;
         }
         Tensor mid = pl.alloc(B, hout, hout, l.mid);
         mid.split = cat.split;   // bf16x3 mode: conv_a -> conv_b hand-off stays in split bf16 form
@@ -560,6 +597,7 @@ static int build_aerial_plan(ccvpe_handle_s* h, Plan& pl, int B) {
             p.dst[0] = {c.cache_out, D, 0}; p.ndst = 1;
             c.launch_conv(p, tile);
         }, 2.0 * B * 64 * 5120.0 * D, 4.0 * (B * 256 * 1280.0 + 5120.0 * D));
+        pl.ops.back().proj_ok = pc->proj != nullptr && h->cfg.reserved[0] == 0;   // (the same candidates - the same tuning-table entry - as the full plan's launch)
     }
     for (int t = 0; t < 5; ++t) {
         Tensor tp = senc.tap[TAP_BLOCK[t]];

@@ -141,7 +141,7 @@ int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
             if (conv_igemm_tile_is_proj(t)) {
                 const int rt = conv_igemm_tile_proj_rt(t);   // row tiles per workgroup; >= 100: the latency form (small M only)
                 if (!op.proj_ok || !conv_proj_has(rt, op.gemm_n) || getenv("CCVPE_NO_PW")) continue;
-                if (rt >= 100 && (op.gemm_m > 4096 || op.gemm_kpad > 1280)) continue;
+                if (rt >= 100 && (op.gemm_m > 4096 || op.gemm_kpad > 10240)) continue;   // (conv_proj_supported has the exact rule)
             } else if (conv_igemm_tile_is_pw(t)) {
                 ConvParams qq{}; qq.M = 16; qq.N = 1 << 20;
                 const int bn = (int)(((long long)qq.N) / conv_igemm_tile_blocks(qq, t));   // the tile's column width
@@ -164,10 +164,12 @@ int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
                     if (blocks >= (wino ? 2048 : 512) || blocks * split > (wino ? 8192 : 2048) || nkt < 4 * split) break;
                     if ((size_t)split * op.gemm_m * op.gemm_n > Plan::SPLITK_FLOATS) break;
                 }
-                const int cfg = t | (split << 8);
+                for (int fuse = 0; fuse < 2; ++fuse) {   // a split launch: with the reduce launch, and reducing itself (ticket.h) where the kernel can
+                if (fuse && (split <= 1 || split == 255 || !conv_igemm_tile_can_fuse_split(t) || pl.tickets == nullptr || getenv("CCVPE_TUNE_NO_FUSED_SPLIT"))) break;
+                const int cfg = t | ((fuse ? split + SPLIT_FUSED : split) << 8);
                 *op.tile = cfg;
                 op.fn(c);   // warm-up (also sets the dynamic-LDS attribute on first use)
-                if (split == 255 && (conv_igemm_last_tile() >> 8) != 255) continue;   // tail split not applicable to this grid
+                if (split == 255 && (conv_igemm_last_tile() >> 8) != 255) break;   // tail split not applicable to this grid
                 float ms = 1e30f;
                 for (int trial = 0; trial < 3; ++trial) {   // min of three timed pairs: one noisy sample must not pick the tile
                     HIPCHK(hipEventRecord(e0, nullptr));
@@ -181,8 +183,9 @@ int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
                 }
                 static const char* verbose = getenv("CCVPE_TUNE_VERBOSE");   // dev: print every candidate of the launches whose name contains the string
                 if (verbose && op.name.find(verbose) != std::string::npos)
-                    std::fprintf(stderr, "tune %-28s %-28s split %3d: %8.1f us\n", op.name.c_str(), conv_igemm_tile_name(t), split, 500.0 * ms);
+                    std::fprintf(stderr, "tune %-28s %-28s split %3d%s: %8.1f us\n", op.name.c_str(), conv_igemm_tile_name(t), split, fuse ? " self-reducing" : "", 500.0 * ms);
                 if (ms < best_ms) { best_ms = ms; best = cfg; }
+                }
             }
         }
         *op.tile = best;

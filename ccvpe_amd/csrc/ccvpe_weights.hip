@@ -93,9 +93,13 @@ int pack_conv(ccvpe_handle_s* h, PackedConv& pc, int N, int taps, int cin, int c
     pc.N = N; pc.Kpad = kpad; pc.nchunks = K / 8; pc.cinp = cinp; pc.KH = KH; pc.KW = KW;
     int rc = upload(h, w, &pc.w);
     if (rc) return rc;
-    if (KH == 1 && KW == 1 && taps == 1 && cin == cinp && conv_proj_wanted(N, cin) && !getenv("CCVPE_NO_PROJ")) {
+    if (((KH == 1 && KW == 1 && taps == 1 && cin == cinp && conv_proj_wanted(N, cin)) || conv_proj_lat_wanted(taps, KH, KW, cinp)) && !getenv("CCVPE_NO_PROJ")) {
+        // fragment-order copy for kernels_proj.hip; columns follow the packed channel positions (cmap: the [8 | C] layout of the
+        // decoder's transposed convs has zero columns where the score padding sits)
+        std::vector<int> inv(cinp, -1);
+        for (int c = 0; c < cin; ++c) inv[cmap[c]] = c;
         std::vector<float> up;
-        conv_proj_pack(N, cin, [&](int n, int c) { return get(n, 0, c); }, up);
+        conv_proj_pack(N, cinp, [&](int n, int k) { const int t = k / cinp, c = inv[k - t * cinp]; return c >= 0 ? get(n, t, c) : 0.f; }, up, taps);
         pc.proj_bytes = up.size() * sizeof(float);
         if ((rc = upload(h, up, &pc.proj))) return rc;
     }

@@ -109,4 +109,76 @@ __device__ __forceinline__ void emit_out4(const ConvParams& p, int m, int n, f32
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Self-reducing split-K (ticket.h).  Every K slice of an output region has stored its partial sums to its slab (slab z = blockIdx.z,
+// layout [z][M][N], WRITE-THROUGH stores); the workgroup calls splitk_ticket() - all threads, after its last slab store - and, when it
+// drew the last of the S tickets, splitk_finish(): the region's outputs = bias + sum over z = 0 .. S - 1 of the slabs (slice order: the
+// same bits whoever arrives last, the same bits as splitk_reduce_kernel), activation, emit_out4 (residual, pixel shuffle, concat taps).
+// Region = `rows` runs of `cols` consecutive GEMM rows, `wpitch` rows apart, starting at GEMM row pix0; columns [n0, n0 + nch).
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool splitk_ticket(const ConvParams& p, int region, unsigned* lds_flag) {
+    return ticket_arrive(p.tickets + region, 1u, (unsigned)p.splitk, lds_flag);
+}
+
+template <int NT>
+__device__ __forceinline__ void splitk_finish(const ConvParams& p, int pix0, int rows, int cols, int wpitch, int n0, int nch) {
+    const unsigned zstride = (unsigned)p.M * (unsigned)p.N * 4u;
+    const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, (unsigned)p.splitk * zstride, 0x00020000);
+    const int S = p.splitk;
+    if ((p.N & 3) == 0) {
+        const int c4 = nch >> 2, total = rows * cols * c4;
+        constexpr int PB = 4;                                      // positions per round; 4 slabs of each in flight
+        for (int it0 = threadIdx.x; it0 < total; it0 += NT * PB) {
+            unsigned off[PB];
+            int mm[PB], nn[PB];
+            f32x4 v[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int it = it0 + u * NT;
+                const int q = it % c4, px = it / c4;
+                const int y = px / cols, x = px - y * cols;
+                mm[u] = pix0 + y * wpitch + x; nn[u] = n0 + 4 * q;
+                const bool ok = it < total && mm[u] < p.M && nn[u] < p.N;
+                off[u] = ok ? (unsigned)(mm[u] * p.N + nn[u]) * 4u : 0x80000000u;
+                if (!ok) mm[u] = -1;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int z0 = 0; z0 < S; z0 += 4) {
+                f32x4 t[PB][4];
+#pragma unroll
+                for (int u = 0; u < PB; ++u)
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) t[u][z] = ld_sc1_f4(slab, (z0 + z < S && mm[u] >= 0) ? off[u] + (unsigned)(z0 + z) * zstride : 0x80000000u);
+#pragma unroll
+                for (int u = 0; u < PB; ++u)
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) v[u] += t[u][z];    // (slices past S: + 0)
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                if (mm[u] < 0) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = apply_act(v[u][e] + p.bias[nn[u] + e], p.act);
+                emit_out4(p, mm[u], nn[u], v[u]);
+            }
+        }
+    } else {   // widths that are not a multiple of 4: element-wise (rare: only the narrow descriptor layers)
+        const int total = rows * cols * nch;
+        for (int it = threadIdx.x; it < total; it += NT) {
+            const int c = it % nch, px = it / nch;
+            const int y = px / cols, x = px - y * cols;
+            const int m = pix0 + y * wpitch + x, n = n0 + c;
+            if (m >= p.M || n >= p.N || (c & 3) != 0) continue;    // one thread per group of four columns (emit_out4 places a quad)
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < S; ++z)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.N) v[e] += ld_sc1(p.partial + ((size_t)z * p.M + m) * p.N + n + e);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e] + (n + e < p.N ? p.bias[n + e] : 0.f), p.act);
+            emit_out4(p, m, n, v);
+        }
+    }
+}
+
 }  // namespace ccvpe

@@ -79,6 +79,11 @@ struct ConvParams {
     int splitk;                // filled by launch_conv_igemm from the cfg word: K split over gridDim.z
     float* partial;            // split-K slab scratch [splitk][M][N] (null = split-K unavailable)
     size_t partial_floats;
+    // Self-reducing split-K (round 4, ticket.h): the K slices of an output region draw tickets on tickets[region]; the last one sums the
+    // slabs in slice order and runs the epilogue itself - no splitk_reduce_kernel launch.  Chosen per launch by the cfg word (split code
+    // 64 + S); needs `tickets` (>= CONV_TICKETS counters, zero between launches).
+    unsigned* tickets;
+    int split_fused;           // filled by launch_conv_igemm
     // exact division by W and H for the transposed-conv pixel shuffle (filled by conv_igemm_prepare): q = (umulhi(n, mul) + n) >> shift
     unsigned fdw_mul, fdw_shift, fdh_mul, fdh_shift;
     // Winograd F(2x2,3x3) form of a 3x3 / stride 1 / pad 1 layer (kernels_wino.hip); null = not packed
@@ -99,10 +104,21 @@ struct ConvParams {
     // split F(4x4) form (kernels_wino4p.hip): per-stream scratch for the pre-transformed input V = B^T d B (null = unavailable)
     float* wino4_v;
     size_t wino4_v_floats;
+    // Squeeze-excite in the prologue of the latency-form project GEMM (kernels_proj.hip, batch <= 4; model.py:113-118): instead of a gate
+    // vector the launch gets the fused front kernel's per-item squeeze rows (ticket.h: SeTicket::sqpart) and the excite weights, and
+    // every wave computes the gates of ITS K slice while its operands are in flight.  se_rows == null: `gate` as usual.
+    const float* se_rows;      // [B][se_nrows][se_sq]
+    int se_nrows, se_sq;
+    float se_inv_hw;
+    const float* se_b1;        // [SQ]
+    const float* se_w2;        // [SQ][Cin]
+    const float* se_b2;        // [Cin]
 };
 
 // tile = 0 picks automatically from (M, N); otherwise one of the TILE_* ids.
-enum { TILE_AUTO = 0 };      // tile ids are 1..conv_igemm_num_tiles(); a launch cfg word is tile | (splitk << 8)
+enum { TILE_AUTO = 0 };
+static constexpr int CONV_TICKETS = 8192;   // ticket counters a convolution launch may use (output regions of a split-K launch)
+static constexpr int SPLIT_FUSED = 64;       // split code 64 + S: S slices, reduced by the last arriver (S <= 32)      // tile ids are 1..conv_igemm_num_tiles(); a launch cfg word is tile | (splitk << 8)
 int conv_igemm_num_tiles();
 double conv_igemm_tile_util(const ConvParams& p, int tile);
 long long conv_igemm_tile_blocks(const ConvParams& p, int tile);
@@ -111,6 +127,7 @@ int conv_igemm_k_index(int cin, int taps, int tap, int c);   // packed-weight co
 int launch_conv_igemm(const ConvParams& p, int tile, hipStream_t s);   // 0, or -1 for unsupported geometry
 int conv_igemm_npad();       // row padding of packed weights (multiple every tile divides)
 bool conv_igemm_tile_is_bf16x3(int tile);
+bool conv_igemm_tile_can_fuse_split(int tile);   // the kernel reduces its own split-K when given the split code SPLIT_FUSED + S
 void launch_splitk_reduce(const ConvParams& p, hipStream_t s);
 struct Bf16x3Tile { int bm, bn; const char* name; void (*launch)(const ConvParams&, hipStream_t); };
 int bf16x3_num_tiles();
@@ -148,12 +165,14 @@ bool conv_pw_fits(int bn, int kpad);
 bool conv_pw_tile_ok(int i, const ConvParams& p);   // tile i of the family can run this launch
 int conv_pw_tile_proj_rt(int i);                    // row-tile code of a kernels_proj.hip tile (>= 100: its latency form), 0 for the others
 int conv_igemm_tile_proj_rt(int tile);              // the same by tile id
+int conv_proj_lat_tile();                           // tile id of conv_projl_1 (the latency form with one column tile per workgroup)
 // deep-K project GEMM (kernels_proj.hip)
 bool conv_proj_supported(const ConvParams& p, int rt);
 void launch_proj(const ConvParams& p, int rt, hipStream_t s);
 bool conv_proj_wanted(int N, int cin);
 bool conv_proj_has(int rt, int N);
-size_t conv_proj_pack(int N, int cin, const std::function<float(int, int)>& get, std::vector<float>& out);
+size_t conv_proj_pack(int N, int cin, const std::function<float(int, int)>& get, std::vector<float>& out, int taps = 1);
+bool conv_proj_lat_wanted(int taps, int KH, int KW, int cinp);   // deep-K 1x1 / k2s2 layers the latency form may serve
 bool conv_igemm_tile_is_pw(int tile);
 bool conv_igemm_tile_is_proj(int tile);   // a kernels_proj.hip tile (member of the pointwise family)
 int conv_igemm_last_tile();  // tile id of the most recent launch on this thread (then reset to 0)

@@ -248,6 +248,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
     __syncthreads();
     constexpr int C4 = BN / 4;
+    const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(split ? p.partial : const_cast<float*>(p.in), 0,
+                                                                                split ? (unsigned)p.splitk * (unsigned)p.M * (unsigned)p.N * 4u : 0u, 0x00020000);
     for (int it = tid; it < BM * C4; it += 256) {
         const int ml = it / C4, c4 = it - ml * C4;
         const int m = m0 + ml, n = n0 + c4 * 4;
@@ -255,12 +257,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ml * LDC + c4 * 4);
         if (split) {
             float* dst = p.partial + ((size_t)blockIdx.z * p.M + m) * p.N + n;
-            if ((p.N & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+            if (p.split_fused) {   // write-through: the slabs are handed to the last arriver of this tile (ticket.h)
+                if ((p.N & 3) == 0) st_sc1_f4(slab_rsrc, (unsigned)(((size_t)blockIdx.z * p.M + m) * p.N + n) * 4u, v);
+                else
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) st_sc1(dst + e, v[e]);
+            } else if ((p.N & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
             else
                 for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = v[e];
         } else {
             emit_out4(p, m, n, v);
         }
+    }
+    if (split && p.split_fused) {
+        // self-reducing split-K: the last of this tile's K slices sums the slabs (slice order) and runs the epilogue; the C tile in
+        // LDS is dead behind the ticket's first barrier, its first word serves as the flag
+        if (splitk_ticket(p, blockIdx.y * gridDim.x + blockIdx.x, reinterpret_cast<unsigned*>(Cs)))
+            splitk_finish<256>(p, m0, 1, BM, 0, n0, BN);
     }
 }
 
@@ -297,8 +309,11 @@ static void launch_cfg2(const ConvParams& p, hipStream_t s) {
     auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, MT, GATE, NS>;
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.splitk > 1 ? p.splitk : 1);
+    if (p.splitk <= 1 || p.tickets == nullptr || (long long)grid.x * grid.y > CONV_TICKETS) {
+        if (p.split_fused) { ConvParams q = p; q.split_fused = 0; hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q); if (q.splitk > 1) launch_splitk_reduce(q, s); return; }
+    }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
-    if (p.splitk > 1) launch_splitk_reduce(p, s);
+    if (p.splitk > 1 && !p.split_fused) launch_splitk_reduce(p, s);
 }
 
 template <int BM, int BN, int WGM, int WGN, int MT, int NS = 2>
@@ -346,6 +361,11 @@ static int pw_index(int tile) { return (tile & 0xff) - NTILES - bf16x3_num_tiles
 bool conv_igemm_tile_is_pw(int tile) { const int i = pw_index(tile); return i >= 0 && i < pw_num_tiles(); }
 bool conv_igemm_tile_is_proj(int tile) { return conv_igemm_tile_is_pw(tile) && pw_tile(pw_index(tile))->proj_rt > 0; }
 int conv_igemm_tile_proj_rt(int tile) { return conv_igemm_tile_is_pw(tile) ? conv_pw_tile_proj_rt(pw_index(tile)) : 0; }
+int conv_proj_lat_tile() {
+    for (int i = 0; i < pw_num_tiles(); ++i)
+        if (pw_tile(i)->proj_rt == 101) return NTILES + bf16x3_num_tiles() + wino_num_tiles() + i + 1;
+    return 0;
+}
 bool conv_igemm_tile_is_wino4(int tile) { return conv_igemm_tile_is_wino(tile) && wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->f == 4; }
 bool conv_igemm_tile_is_wino4p(int tile) { return conv_igemm_tile_is_wino4(tile) && wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->pre; }
 static int wino4x_cfg_of(int tile) { return conv_igemm_tile_is_wino(tile) ? wino_tile((tile & 0xff) - NTILES - bf16x3_num_tiles() - 1)->xcfg : -1; }
@@ -358,6 +378,11 @@ bool conv_wino_tile_supported(const ConvParams& p, int tile) {
     return conv_igemm_tile_is_wino4(tile) ? conv_wino4_supported(p) : conv_wino_supported(p);
 }
 bool conv_igemm_tile_is_bf16x3(int tile) { tile &= 0xff; return tile > NTILES && tile <= NTILES + bf16x3_num_tiles(); }
+// kernels that can reduce their own split-K (split code SPLIT_FUSED + S): the fp32 implicit GEMM and the fused F(4x4) / F(2x2) Winograd kernels
+bool conv_igemm_tile_can_fuse_split(int tile) {
+    tile &= 0xff;
+    return (tile >= 1 && tile <= NTILES) || (conv_igemm_tile_is_wino(tile) && !conv_igemm_tile_is_wino4p(tile) && !conv_igemm_tile_is_wino4x(tile));
+}
 static void tile_dims(int tile, int& bm, int& bn) {
     if (tile >= 1 && tile <= NTILES) { bm = TILES[tile - 1].bm; bn = TILES[tile - 1].bn; }
     else if (conv_igemm_tile_is_bf16x3(tile)) { bm = (*bf16x3_tile(tile - NTILES - 1)).bm; bn = (*bf16x3_tile(tile - NTILES - 1)).bn; }
@@ -480,6 +505,8 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
         if (p.dst[d].split && !p.vec_epi) return -1;   // split destinations exist only on the 16-byte path
     int splitk = (tile >> 8) & 0xff;
     tile &= 0xff;
+    bool fused = false;
+    if (splitk > SPLIT_FUSED && splitk <= SPLIT_FUSED + 32) { fused = p.tickets != nullptr; splitk -= SPLIT_FUSED; }   // (no counters: the reduce launch)
     if (conv_igemm_tile_is_bf16x3(tile) && (p.w_hi == nullptr || p.w_lo == nullptr)) tile = 0;   // planes not packed: fp32 path
     if (conv_igemm_tile_is_wino(tile) && !conv_wino_tile_supported(p, tile)) tile = 0;
     if (conv_igemm_tile_is_pw(tile) && !conv_pw_tile_ok(pw_index(tile), p)) tile = 0;   // not a layer this pointwise tile takes
@@ -492,7 +519,10 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
     if (splitk == 255) { if (!conv_igemm_tile_is_wino4(tile) || conv_igemm_tile_is_wino4x(tile) || p.partial == nullptr) splitk = 1; }   // F(4x4) tail split: sized by its launcher
     else if (splitk < 2 || p.partial == nullptr || (size_t)splitk * p.M * p.N > p.partial_floats) splitk = 1;
     p.splitk = splitk;
-    g_last_tile = tile | (splitk << 8);
+    // which kernels reduce their own split: the fp32 implicit GEMM, the F(4x4) and F(2x2) Winograd kernels
+    fused = fused && splitk > 1 && splitk != 255 && conv_igemm_tile_can_fuse_split(tile);
+    p.split_fused = (fused || (splitk == 255 && p.tickets != nullptr)) ? 1 : 0;       // (the tail split's K-split sub-launch reduces itself whenever it can)
+    g_last_tile = tile | ((fused ? splitk + SPLIT_FUSED : splitk) << 8);
     if (tile <= NTILES) TILES[tile - 1].launch(p, s);
     else if (conv_igemm_tile_is_pw(tile)) pw_tile(pw_index(tile))->launch(p, s);
     else if (conv_igemm_tile_is_wino(tile)) wino_tile(tile - NTILES - bf16x3_num_tiles() - 1)->launch(p, s);

@@ -177,8 +177,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
     const int se_b0 = it_lo / max(p.se.per_sample, 1);
     const bool se_single = (it_hi - 1) / max(p.se.per_sample, 1) == se_b0;   // this share lies inside one sample
     const bool se_on = p.se.counter != nullptr;            // per_sample == NST * nchunks items complete a sample
-    const bool sq_lane = se_on && wave == 0 && lane < p.se.SQ;
-    const __amdgpu_buffer_rsrc_t se_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(se_on ? p.se.w1 : p.we), 0, se_on ? (unsigned)((size_t)p.se.SQ * p.mid * 4) : 0u, 0x00020000);
+    const bool rows_on = p.se.sqpart != nullptr;           // squeeze rows per item: for the ticket's combining step, or (no ticket) for the project GEMM's prologue
+    const bool sq_lane = rows_on && wave == 0 && lane < p.se.SQ;
+    const __amdgpu_buffer_rsrc_t se_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rows_on ? p.se.w1 : p.we), 0, rows_on ? (unsigned)((size_t)p.se.SQ * p.mid * 4) : 0u, 0x00020000);
     Unit cur = decode_unit(it_lo / q.nchunks);
     {
         const int ch = it_lo - (it_lo / q.nchunks) * q.nchunks;
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
 #pragma unroll
                 for (int w = 0; w < NT / 64; ++w) s += red[w * 16 + lane];
             }
-            if (!se_on) {
+            if (!rows_on) {
                 if (lane < 16) p.pool[(size_t)unit * p.mid + ch0 + lane] = s;   // [B][NST][mid]: one partial row per strip (launch_se reads them)
             } else {
                 // this item's share of the squeeze conv (model.py:115 is linear in the pooled sums): lane j adds w1[j][ch0 + c] * sum[c]

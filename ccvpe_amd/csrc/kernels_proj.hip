@@ -137,58 +137,175 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // fifteen partial sums in LDS, in wave order.  No slab, no second launch; the grid is (row tiles, column blocks) = 16 x 6-12 workgroups.
 // ---------------------------------------------------------------------------------------------------------------------------------
 static constexpr int PL_WAVES = 16;
-static constexpr int PL_STEPS = 5;             // steps a wave holds at most: K <= 16 x 5 x 16 = 1280 channels
-template <int CTB, bool GATE>
+// LS = steps a wave requests at once (a group); K deeper than 16 x LS x 16 channels takes several groups.  The same kernel serves
+// (a) the gated project convs (1x1), (b) 1x1 layers without a gate: the ground descriptor heads (models.py:355-395) and the transposed
+// convs of the first decoder levels (models.py:407-446; k2s2 transposed = 1x1 with a pixel-shuffle epilogue, emit_out4), (c) the aerial
+// descriptor conv k2s2 (models.py:471-482): four taps on disjoint pixels, K = (tap, channel), a lane keeps one base address per tap.
+// Channels are padded to 16 per tap (zero weights; the activation read runs into the next pixel's first channels - finite numbers - or
+// past the tensor - zeros).
+// SEP (GATE must be set too): the squeeze-excite gates are computed HERE.  All threads sum the front kernel's squeeze rows (a row of SQ
+// floats per work item, row order; G groups of SQ threads, the groups meet in LDS) -> sq[j] = swish(b1[j] + mean); then lane (kq, r) of
+// a wave holds channels 16 s + 4 kq .. + 3 of its steps' activations and takes the excite rows j = r, r + 16, ...: three 16-byte loads
+// per step for SQ = 48, a butterfly over the 16 lanes of a quad, a sigmoid - the gate quad lands in the lane that multiplies it into
+// its A fragment.  Every request (activations, weights, excite rows, squeeze rows) goes out before the first wait.
+template <int CTB, bool GATE, int LS, bool SEP>
 __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const ConvParams p) {
+    static_assert(!SEP || GATE, "SEP computes what GATE multiplies");
     constexpr unsigned OOB = 0x80000000u;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [16 waves][CTB][64 lanes][4]
+    constexpr int SEJ = 3;                                         // excite rows per lane and step: SQ <= 16 * SEJ = 48 (EfficientNet-B0: <= 48)
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [16 waves][CTB][64 lanes][4]; SEP: group partials and sq[] first
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq4 = 4 * (lane >> 4);
-    const int hw = p.OH * p.OW;
-    const int nsteps = p.Cin >> 4;
-    const int per = (nsteps + PL_WAVES - 1) / PL_WAVES;            // <= PL_STEPS (checked by the launcher)
+    const int ohw = p.OH * p.OW;
+    const int taps = p.KH * p.KW;
+    const int spt = (p.Cin + 15) >> 4;                             // steps per tap
+    const int nsteps = spt * taps;
+    const int per = (nsteps + PL_WAVES - 1) / PL_WAVES;
     const int s_begin = min(wave * per, nsteps), s_end = min(s_begin + per, nsteps);
     const int m0 = blockIdx.x * 16;
     const int ct_all = (p.N + 15) >> 4, t0 = blockIdx.y * CTB;
 
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE ? p.gate : p.in), 0, GATE ? p.gate_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t g_rsrc = SEP ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.se_w2), 0, (unsigned)((size_t)p.se_sq * p.Cin * 4), 0x00020000)
+                                              : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE ? p.gate : p.in), 0, GATE ? p.gate_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.proj_w), 0, p.proj_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SEP ? p.se_b2 : p.in), 0, SEP ? (unsigned)(p.Cin * 4) : 0u, 0x00020000);
     const int m = m0 + (lane & 15);
     const bool ok = m < p.M;
-    const unsigned a_off = ok ? (unsigned)m * (unsigned)p.in_ld * 4u + (unsigned)kq4 * 4u : OOB;
-    const unsigned g_off = ok ? (unsigned)(m / hw) * (unsigned)p.Cin * 4u + (unsigned)kq4 * 4u : OOB;
+    // base address of this lane's row per tap (1x1: the row itself; k2s2: the four pixels of its 2 x 2 patch)
+    unsigned a_tap[4];
+    {
+        const int mm = ok ? m : 0;
+        const int b = mm / ohw, rem = mm - b * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+#pragma unroll
+        for (int t = 0; t < (SEP ? 1 : 4); ++t) {
+            const int ky = t / p.KW, kx = t - ky * p.KW;
+            const int iy = oy * p.stride + ky, ix = ox * p.stride + kx;
+            a_tap[t] = (ok && t < taps) ? (unsigned)((b * p.H + iy) * p.W + ix) * (unsigned)p.in_ld * 4u + (unsigned)kq4 * 4u : OOB;
+        }
+    }
+    const unsigned g_off = ok ? (unsigned)(m / ohw) * (unsigned)p.Cin * 4u + (unsigned)kq4 * 4u : OOB;
     const unsigned w_lane = (unsigned)lane * 16u;
 
-    // every operand of this wave's steps, requested at once (steps past s_end and column tiles past the layer's ask for out-of-range
-    // offsets: zeros, no traffic)
-    f32x4 a[PL_STEPS], g[PL_STEPS], w[PL_STEPS][CTB];
-#pragma unroll
-    for (int i = 0; i < PL_STEPS; ++i) {
-        const int s = s_begin + i;
-        const bool live = s < s_end;
-        a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, live ? a_off : OOB, s * 64, 0));
-        if (GATE) g[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, live ? g_off : OOB, s * 64, 0));
-#pragma unroll
-        for (int t = 0; t < CTB; ++t)
-            w[i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (live && t0 + t < ct_all) ? w_lane : OOB, (s * ct_all + t0 + t) * 1024, 0));
-    }
-    __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the requests between the MFMAs to save registers: one memory latency per step)
     f32x4 acc[CTB];
 #pragma unroll
     for (int t = 0; t < CTB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // SEP: this thread's share of the squeeze rows (requested first; summed behind the operand requests of the first group)
+    const int se_g = SEP ? tid / max(p.se_sq, 1) : 0, se_j = SEP ? tid - se_g * p.se_sq : 0;
+    const int se_G = SEP ? min(64 * PL_WAVES / max(p.se_sq, 1), 16) : 1;      // groups: rows g, g + G, ...
+    float se_b1v = 0.f;                                            // bias of squeeze output tid (requested with everything else)
+    constexpr int SEU = 6;                                         // squeeze rows per thread: <= 6 x 16 groups
+    float se_v[SEU];
+    if (SEP) {
+        // (buffer loads with 32-bit offsets: per-thread 64-bit addresses of six loads are twelve registers this kernel does not have)
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.se_rows) + (size_t)(m0 / ohw) * p.se_nrows * p.se_sq, 0,
+                                                                                 (unsigned)((size_t)p.se_nrows * p.se_sq * 4), 0x00020000);   // (a row tile lies inside one sample: checked by the host)
 #pragma unroll
-    for (int i = 0; i < PL_STEPS; ++i) {
-        if (GATE) a[i] *= g[i];
-#pragma unroll
-        for (int t = 0; t < CTB; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].x, a[i].x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].y, a[i].y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].z, a[i].z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].w, a[i].w, acc[t], 0, 0, 0);
+        for (int u = 0; u < SEU; ++u) {
+            const int r = se_g + u * se_G;
+            se_v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, (se_g < se_G && r < p.se_nrows) ? (unsigned)((r * p.se_sq + se_j) * 4) : OOB, 0, 0));
         }
+        const __amdgpu_buffer_rsrc_t b1_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.se_b1), 0, (unsigned)(p.se_sq * 4), 0x00020000);
+        se_b1v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b1_rsrc, (unsigned)(tid * 4), 0, 0));   // (threads past SQ: out of range, zero)
     }
+    // SEP, second batch of requests - behind the barriers of the squeeze sums: excite rows
+    // 32 .. 47 (blocks 12-15 only; out of range - no traffic - elsewhere).  The activations (L2: the front kernel just wrote them) follow
+    // step by step as the excite rows leave their registers: all four kinds in one batch needed more than the 128 registers a wave has
+    // with sixteen waves on a CU.
+#define CCVPE_PL_LATE_REQUESTS()                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < LS; ++i) {                                                                                \
+        const int s_ = sg + i, j_ = (lane & 15) + 16 * (SEJ - 1);                                                                     \
+        ew[i][SEJ - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (s_ < s_end && j_ < p.se_sq) ? (unsigned)((j_ * p.Cin + kq4) * 4) : OOB, s_ * 64, 0)); \
+    }
+    int sg = s_begin;
+#pragma unroll 1
+    do {   // (at least one pass per wave, also for a wave without steps - all its requests out of range: the SEP barriers below are for everybody)
+        // every operand of the group, requested at once (steps past s_end and column tiles past the layer's ask for out-of-range
+        // offsets: zeros, no traffic)
+        f32x4 a[LS], g[LS], w[LS][CTB];
+        f32x4 ew[SEP ? LS : 1][SEP ? SEJ : 1];
+#pragma unroll
+        for (int i = 0; i < LS; ++i) {
+            const int s = sg + i;
+            const bool live = s < s_end;
+            const int tap = taps == 1 ? 0 : s / spt;                 // (scalar: s is wave-uniform)
+            const int sub = s - tap * spt;
+            const unsigned ab = tap == 0 ? a_tap[0] : tap == 1 ? a_tap[1] : tap == 2 ? a_tap[2] : a_tap[3];
+            if (!SEP) a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, live ? ab : OOB, sub * 64, 0));
+            if (SEP) {
+#pragma unroll
+                for (int e = 0; e < SEJ - 1; ++e) {   // excite row j = (lane & 15) + 16 e at channels 16 s + 4 kq .. + 3 (rows 32 .. 47: below)
+                    const int j = (lane & 15) + 16 * e;
+                    ew[i][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (live && j < p.se_sq) ? (unsigned)((j * p.Cin + kq4) * 4) : OOB, sub * 64, 0));
+                }
+            } else if (GATE) g[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, live ? g_off : OOB, sub * 64, 0));
+#pragma unroll
+            for (int t = 0; t < CTB; ++t)
+                w[i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (live && t0 + t < ct_all) ? w_lane : OOB, (s * ct_all + t0 + t) * 1024, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the requests between the MFMAs to save registers: one memory latency per step)
+        if (SEP) {
+            float* part = smem + PL_WAVES * CTB * 256;               // [G][SQ] group sums, then sq[SQ]: behind the exchange area (a fast wave may
+            float* sq = part + 16 * 64;                              //  already write its partial sums while a slow one still reads sq)
+            if (sg == s_begin) {                                     // (uniform per wave; every wave has at least one group - see the launcher)
+                float sum = 0.f;
+#pragma unroll
+                for (int u = 0; u < SEU; ++u) sum += se_v[u];
+                if (se_g < se_G) part[se_g * p.se_sq + se_j] = sum;
+                __syncthreads();
+                if (tid < p.se_sq) {
+                    float v = 0.f;
+                    for (int g2 = 0; g2 < se_G; ++g2) v += part[g2 * p.se_sq + tid];
+                    v = v * p.se_inv_hw + se_b1v;
+                    sq[tid] = v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
+                }
+                __syncthreads();
+            }
+            CCVPE_PL_LATE_REQUESTS();
+            float sqv[SEJ];
+#pragma unroll
+            for (int e = 0; e < SEJ; ++e) sqv[e] = (lane & 15) + 16 * e < p.se_sq ? sq[(lane & 15) + 16 * e] : 0.f;
+#pragma unroll
+            for (int i = 0; i < LS; ++i) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < SEJ; ++e) z += ew[i][e] * sqv[e];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) z[c] += __shfl_xor(z[c], off);
+                const int s = sg + i;
+                const int sub = s < s_end ? s - (taps == 1 ? 0 : s / spt) * spt : 0;
+                const f32x4 b2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b2_rsrc, (unsigned)(kq4 * 4), sub * 64, 0));   // (past Cin: zeros; such a step's activations are zeros too)
+                // the gate multiplies the WEIGHT fragment (already here; lane (kq, n) holds the same four channels of both operands), so
+                // no gate registers wait for the activations: (w g) a instead of w (g a)
+                f32x4 gq;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gq[c] = 1.f / (1.f + __expf(-(z[c] + b2[c])));
+#pragma unroll
+                for (int t = 0; t < CTB; ++t) w[i][t] *= gq;
+                __builtin_amdgcn_sched_barrier(0);
+                a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, s < s_end ? a_tap[0] : OOB, s * 64, 0));   // (SEP: one tap)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LS; ++i) {
+            if (GATE && !SEP) a[i] *= g[i];
+#pragma unroll
+            for (int t = 0; t < CTB; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].x, a[i].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].y, a[i].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].z, a[i].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].w, a[i].w, acc[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sg += LS;
+    } while (sg < s_end);
+#undef CCVPE_PL_LATE_REQUESTS
     // ---- the sixteen K-partials meet in LDS; wave t < CTB adds column tile t in wave order and stores it ----
 #pragma unroll
     for (int t = 0; t < CTB; ++t) *reinterpret_cast<f32x4*>(smem + ((wave * CTB + t) * 64 + lane) * 4) = acc[t];
@@ -206,18 +323,23 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
     }
 }
 
+static int proj_lat_steps(const ConvParams& p) { return ((p.Cin + 15) / 16) * p.KH * p.KW; }
+
+template <int CTB, bool GATE, int LS, bool SEP = false>
+static void launch_proj_lat2(const ConvParams& p, hipStream_t s) {
+    constexpr size_t lds = ((size_t)PL_WAVES * CTB * 64 * 4 + (SEP ? 16 * 64 + 64 : 0)) * sizeof(float);
+    const dim3 grid((p.M + 15) / 16, ((p.N + 15) / 16 + CTB - 1) / CTB);
+    static LdsAttr attr;
+    auto kern = conv_proj_lat_kernel<CTB, GATE, LS, SEP>;
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * PL_WAVES), lds, s, p);
+}
 template <int CTB>
 static void launch_proj_lat(const ConvParams& p, hipStream_t s) {
-    constexpr size_t lds = (size_t)PL_WAVES * CTB * 64 * 4 * sizeof(float);
-    const dim3 grid((p.M + 15) / 16, ((p.N + 15) / 16 + CTB - 1) / CTB);
-    static LdsAttr attr_g, attr_n;
-    if (p.gate) {
-        ensure_dynamic_lds(attr_g, reinterpret_cast<const void*>(conv_proj_lat_kernel<CTB, true>), lds);
-        hipLaunchKernelGGL((conv_proj_lat_kernel<CTB, true>), grid, dim3(64 * PL_WAVES), lds, s, p);
-    } else {
-        ensure_dynamic_lds(attr_n, reinterpret_cast<const void*>(conv_proj_lat_kernel<CTB, false>), lds);
-        hipLaunchKernelGGL((conv_proj_lat_kernel<CTB, false>), grid, dim3(64 * PL_WAVES), lds, s, p);
-    }
+    if (p.se_rows) { launch_proj_lat2<1, true, 5, true>(p, s); return; }   // (gates in the prologue: one column tile per workgroup - registers)
+    if (p.gate) { launch_proj_lat2<(CTB > 2 ? 2 : CTB), true, 5>(p, s); return; }   // (never CTB 4 with a gate: conv_proj_supported)
+    if (CTB == 1 && proj_lat_steps(p) > PL_WAVES * 5) { launch_proj_lat2<1, false, 10>(p, s); return; }   // deep K: ten steps per group
+    launch_proj_lat2<CTB, false, 5>(p, s);
 }
 
 struct ProjCfg { int rt, ct; };
@@ -240,9 +362,21 @@ static int proj_ct(const ConvParams& p) { return (p.N + 15) / 16; }
 // rt >= 100: the latency form with rt - 100 column tiles per workgroup (any layer width; K <= 1280; a few thousand rows at most - beyond
 // that its (row tile, column block) grid re-reads the operands too often to be worth timing)
 bool conv_proj_supported(const ConvParams& p, int rt) {
-    if (rt >= 100)
-        return p.proj_w != nullptr && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.OH == p.H && p.OW == p.W && !p.in_split &&
-               p.mode == MODE_CONV && p.Cin % 16 == 0 && p.in_ld % 4 == 0 && p.Cin >= 64 && (p.Cin >> 4) <= PL_WAVES * PL_STEPS && p.M <= 4096;
+    if (rt >= 100) {
+        const bool one = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.OH == p.H && p.OW == p.W;
+        const bool k2s2 = p.KH == 2 && p.KW == 2 && p.stride == 2 && p.OH * 2 == p.H && p.OW * 2 == p.W && p.gate == nullptr && p.mode == MODE_CONV;
+        if (!(p.proj_w != nullptr && (one || k2s2) && p.pad_t == 0 && p.pad_l == 0 && !p.in_split && (p.mode == MODE_CONV || p.mode == MODE_DECONV) &&
+              p.in_ld % 4 == 0 && p.Cin >= 64 && p.M <= 4096)) return false;
+        if ((p.gate != nullptr || p.se_rows != nullptr) && p.Cin % 16 != 0) return false;      // (the gate vector has exactly Cin entries per sample)
+        if (rt == 104 && p.gate != nullptr) return false;              // (gates + four column tiles of weights per step: past the 128 registers of a wave)
+        if (p.se_rows != nullptr) {   // gates computed in the prologue: one group per wave, every wave busy, a row tile inside one sample, <= 64 squeeze outputs
+            const int steps = proj_lat_steps(p);
+            if (rt != 101 || !one || steps > PL_WAVES * 5 || p.se_sq > 48 || p.se_sq < 1 || p.se_nrows > 6 * std::min(1024 / p.se_sq, 16) ||
+                !(p.B == 1 || (p.OH * p.OW) % 16 == 0)) return false;
+        }
+        const int steps = proj_lat_steps(p);
+        return steps <= PL_WAVES * 40;
+    }
     if (!(p.proj_w != nullptr && p.gate != nullptr && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.OH == p.H && p.OW == p.W &&
           !p.in_split && p.mode == MODE_CONV && p.Cin % 16 == 0 && p.in_ld % 4 == 0 && p.Cin >= 64)) return false;
     for (int i = 0; i < PROJ_NCFG; ++i)
@@ -271,21 +405,29 @@ void launch_proj(const ConvParams& p, int rt, hipStream_t s) {
     else if (rt == 1 && ct == 20) launch_proj_cfg<1, 20>(p, s);
 }
 
+// ... and for the latency form: any 1x1 layer (projects, descriptor heads, transposed convs) or k2s2 conv (aerial descriptor map) whose
+// K is deep enough that the implicit GEMM splits it at batch 1
+bool conv_proj_lat_wanted(int taps, int KH, int KW, int cinp) {
+    return taps * cinp >= 480 && ((taps == 1 && KH == 1 && KW == 1) || (taps == 4 && KH == 2 && KW == 2));
+}
+
 // layers the packer makes the fragment-order copy for: the gated project convs with a deep K and one of the widths above
 bool conv_proj_wanted(int N, int cin) {
     const int ct = (N + 15) / 16;
     return cin % 16 == 0 && cin >= 192 && (ct == 5 || ct == 7 || ct == 12 || ct == 20);
 }
 
-// `get(n, c)` returns the folded 1x1 weight
-size_t conv_proj_pack(int N, int cin, const std::function<float(int, int)>& get, std::vector<float>& out) {
-    const int ct = (N + 15) / 16, nsteps = cin / 16;
+// `get(n, k)` returns the folded weight of output channel n at GEMM column k = tap * cin + channel; every tap's channels are padded to a
+// multiple of 16 (zero weights): [step = tap * ceil(cin / 16) + c / 16][column tile][lane = (c % 16) / 4 * 16 + n % 16][c % 4]
+size_t conv_proj_pack(int N, int cin, const std::function<float(int, int)>& get, std::vector<float>& out, int taps) {
+    const int ct = (N + 15) / 16, spt = (cin + 15) / 16, nsteps = spt * taps;
     out.assign((size_t)nsteps * ct * 256, 0.f);
     for (int n = 0; n < N; ++n)
-        for (int c = 0; c < cin; ++c) {
-            const int s = c / 16, k = (c % 16) / 4, j = c % 4;
-            out[(((size_t)s * ct + n / 16) * 64 + k * 16 + (n % 16)) * 4 + j] = get(n, c);
-        }
+        for (int t = 0; t < taps; ++t)
+            for (int c = 0; c < cin; ++c) {
+                const int s = t * spt + c / 16, k = (c % 16) / 4, j = c % 4;
+                out[(((size_t)s * ct + n / 16) * 64 + k * 16 + (n % 16)) * 4 + j] = get(n, t * cin + c);
+            }
     return out.size();
 }
 

@@ -35,8 +35,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // NW channel slices (16 output channels each) x NM tile sets (8 x 4 tiles each, stacked vertically) per workgroup,
 // one wave per (slice, set); GC = 8-channel chunks per raw-patch refresh.
-template <int NW, int NM, int GC>
-__global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino_kernel(const ConvParams p) {
+template <int NW, int NM, int GC, bool FUSED = false>
+__global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino_kernel(const ConvParams p) {   // FUSED: see conv_wino4_kernel
     constexpr int NT = NW * NM * 64;
     constexpr int NITEM = 256 * NM;                        // (tile, channel) transform items per chunk
     constexpr int ITEMS = (NITEM + NT - 1) / NT;
@@ -73,6 +73,9 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
     const int item_end = item_begin + (total >> 3) + (xcd < (total & 7) ? 1 : 0);
     int item = item_begin + ((int)blockIdx.x >> 3);
     if (item >= item_end) return;
+    const int item_first = item;
+    int ordinal = 0;                     // items this workgroup has finished
+    unsigned long long fin_mask = 0;     // self-reducing split-K: ordinals of the regions it is the last K slice of
 
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wino_w), 0, p.wino_bytes, 0x00020000);
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = y[dx][i] < lo ? lo : y[dx][i];
                         const int soff = (((h * 4 + a) * p.W + dx) * ld) * 4;   // uniform
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), o_rsrc, o_lane, soff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), o_rsrc, o_lane, soff, FUSED ? 16 : 0);   // (FUSED: slab, write-through - ticket.h)
                         // two wait states before anything may overwrite the store's data registers (gfx950: tests/test_isa_hazard.py)
                         __builtin_amdgcn_sched_barrier(0);
                         asm volatile("s_nop 1");
@@ -340,6 +343,13 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
                 }
             }
         }
+        if (FUSED) {
+            // self-reducing split-K (igemm_common.h): the last K slice of this workgroup's region (NM tile sets of 16 x 8 pixels, NW x 16
+            // channels) sums the slabs and stores it.  The ticket's first barrier ends every wave's reads of the V image, whose first
+            // word then serves as the flag; the next item's raw patch (Rs) is not touched.
+            if (splitk_ticket(p, item, reinterpret_cast<unsigned*>(Vs))) fin_mask |= 1ull << ordinal;   // (summed behind the loop: registers)
+        }
+        if (FUSED) ++ordinal;
         if (!have_n) break;
 #pragma unroll
         for (int x = 0; x < 16; ++x) {
@@ -347,6 +357,13 @@ __global__ __launch_bounds__(NW * NM * 64) __attribute__((amdgpu_waves_per_eu(2,
             acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         item = item_n; nb = nb_n; b = b_n; by = by_n; bx = bx_n; w_base = w_base_n;
+    }
+    while (FUSED && fin_mask) {   // the regions whose last ticket this workgroup drew (<= 64 items per workgroup: the launcher)
+        const int k = __builtin_ctzll(fin_mask);
+        fin_mask &= fin_mask - 1;
+        int nb_f, b_f, by_f, bx_f;
+        CCVPE_WINO_DECODE(item_first + k * stride, nb_f, b_f, by_f, bx_f);
+        splitk_finish<NT>(p, (b_f * p.H + by_f * NM * 8) * p.W + bx_f * 16, 8 * NM, 16, p.W, nb_f * NW * 16, NW * 16);
     }
 #undef CCVPE_WINO_LOAD_RAW
 #undef CCVPE_WINO_STORE_RAW
@@ -366,14 +383,21 @@ static void launch_wino(const ConvParams& p_in, hipStream_t s) {
     }
     constexpr size_t lds = (4096 * NM * (NM == 1 ? 2 : 1) + (8 * NM + 2) * 18 * (GC * 8 + 4)) * sizeof(float);
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    static LdsAttr attr;
-    auto kern = conv_wino_kernel<NW, NM, GC>;
-    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
+    static LdsAttr attr, attr_f;
     const int mblocks = p.B * (p.W >> 4) * (p.H / (8 * NM));
     const int nblocks = (p.wino_n16 + NW - 1) / NW;
     // persistent grid: two workgroups per CU (the register budget allows no more) loop over the tiles
     const int resident = 2 * 256 / (p.splitk > 1 ? p.splitk : 1);
     dim3 grid(std::min(mblocks * nblocks, std::max(resident, 8)), 1, p.splitk > 1 ? p.splitk : 1);
+    if (p.splitk <= 1 || p.tickets == nullptr || mblocks * nblocks > CONV_TICKETS || (mblocks * nblocks + (int)grid.x - 1) / (int)grid.x + 1 > 64) p.split_fused = 0;
+    if (p.split_fused) {
+        auto kern = conv_wino_kernel<NW, NM, GC, true>;
+        ensure_dynamic_lds(attr_f, reinterpret_cast<const void*>(kern), lds);
+        hipLaunchKernelGGL(kern, grid, dim3(NW * NM * 64), lds, s, p);
+        return;
+    }
+    auto kern = conv_wino_kernel<NW, NM, GC, false>;
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, grid, dim3(NW * NM * 64), lds, s, p);
     if (p.splitk > 1) launch_splitk_reduce(p, s);
 }

@@ -62,7 +62,9 @@ __device__ __forceinline__ void w4_at(const float m0, const float m1, const floa
     y3 = fmaf(8.f, d2, d1) + m5;
 }
 
-template <int NW>
+// FUSED: a split-K launch that reduces itself (igemm_common.h) - slab stores write-through, a ticket per item, the sums behind the loop.
+// A template parameter, not a run-time flag: the kernel sits at exactly 256 registers and any extra path in its loop spills.
+template <int NW, bool FUSED = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino4_kernel(const ConvParams p) {
     static_assert(NW == 4 || NW == 8, "waves w and w + 4 share the k-step w & 3 of a 16-channel group");
     constexpr int NT = NW * 64;
@@ -89,6 +91,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int item_end = item_begin + (total >> 3) + (xcd < (total & 7) ? 1 : 0);
     int item = item_begin + ((int)blockIdx.x >> 3);
     if (item >= item_end) return;
+    const int item_first = item;
+    int ordinal = 0;                     // items this workgroup has finished
+    unsigned long long fin_mask = 0;     // self-reducing split-K: ordinals of the regions it is the last K slice of
 
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wino4_w), 0, p.wino4_bytes, 0x00020000);
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         v[i] = t < lo ? lo : t;
                     }
                     const int soff = ((a * p.W + c) * ld) * 4;   // uniform
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), o_rsrc, o_lane, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), o_rsrc, o_lane, soff, FUSED ? 16 : 0);   // (FUSED: slab, write-through - ticket.h)
                     // gfx950: a vector instruction that overwrites the data registers of a 16-byte buffer store in the very next
                     // issue slot can reach the registers before the store has read them (seen with v_pk_add_f32 behind a store
                     // with an SGPR soffset, which hipcc's hazard recogniser exempts): lanes 12-15 of every row stored the NEXT
@@ -333,10 +338,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
+        if (FUSED) {
+            // self-reducing split-K (igemm_common.h): the last K slice of this (pixel block, channel block) sums the slabs and stores the
+            // block; the V image is free here (its first word is the ticket's flag), the raw patch of the next item is not touched
+            // (the sum itself runs behind the loop: next to the loop's prefetch state its registers spill)
+            if (splitk_ticket(p, item, reinterpret_cast<unsigned*>(Vs))) fin_mask |= 1ull << ordinal;
+        }
+        if (FUSED) ++ordinal;
         if (!have_n) break;
 #pragma unroll
         for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
         item = item_n; nb = nb_n; b = b_n; by = by_n; bx = bx_n; w_base = w_base_n;
+    }
+    // the regions whose last ticket this workgroup drew (the launcher keeps a workgroup's items <= 64 when the launch reduces itself)
+    while (FUSED && fin_mask) {
+        const int k = __builtin_ctzll(fin_mask);
+        fin_mask &= fin_mask - 1;
+        int nb_f, b_f, by_f, bx_f;
+        CCVPE_W4_DECODE(item_first + k * stride, nb_f, b_f, by_f, bx_f);
+        splitk_finish<NT>(p, (b_f * p.H + by_f * 16) * p.W + bx_f * 16, 16, 16, p.W, nb_f * NW * 16, NW * 16);
     }
 #undef CCVPE_W4_DECODE
 #undef CCVPE_W4_ROFF
@@ -356,13 +376,20 @@ static void launch_wino4_plain(const ConvParams& p_in, hipStream_t s) {
     }
     constexpr size_t lds = (W4_VFLOATS + W4_GCH * W4_PLANE) * sizeof(float);
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    static LdsAttr attr;
-    auto kern = conv_wino4_kernel<NW>;
-    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
+    static LdsAttr attr, attr_f;
     const int mblocks = p.B * (p.W >> 4) * (p.H >> 4);
     const int nblocks = p.wino_nb ? p.wino_nb : (p.wino_n16 + NW - 1) / NW;
     const int resident = (NW == 4 ? 2 : 1) * 256 / (p.splitk > 1 ? p.splitk : 1);   // 256-thread workgroups: two per CU, 512-thread: one
     dim3 grid(std::min(mblocks * nblocks, std::max(resident, 8)), 1, p.splitk > 1 ? p.splitk : 1);
+    if (p.splitk <= 1 || p.tickets == nullptr || mblocks * nblocks > CONV_TICKETS || (mblocks * nblocks + (int)grid.x - 1) / (int)grid.x + 1 > 64) p.split_fused = 0;
+    if (p.split_fused) {
+        auto kern = conv_wino4_kernel<NW, true>;
+        ensure_dynamic_lds(attr_f, reinterpret_cast<const void*>(kern), lds);
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+        return;
+    }
+    auto kern = conv_wino4_kernel<NW, false>;
+    ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
     if (p.splitk > 1) launch_splitk_reduce(p, s);
 }
@@ -394,7 +421,7 @@ static void launch_wino4(const ConvParams& p, hipStream_t s) {
         return;
     }
     g_tail_applied = true;
-    a.wino_nb = nblocks - tail_nb;
+    a.wino_nb = nblocks - tail_nb; a.split_fused = 0;
     launch_wino4_plain<NW>(a, s);
     ConvParams b = p;
     b.wino_nb = tail_nb; b.wino_n16_off = (nblocks - tail_nb) * NW;

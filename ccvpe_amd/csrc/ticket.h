@@ -49,7 +49,9 @@ __device__ __forceinline__ bool ticket_arrive(unsigned* counter, unsigned n, uns
         *flag = last ? 1u : 0u;
     }
     __syncthreads();
-    return *flag != 0u;
+    const bool last = *flag != 0u;
+    __syncthreads();   // (the callers' flag word is scratch they reuse at once: nobody rewrites it before everybody has read it)
+    return last;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

@@ -146,6 +146,33 @@ def test_winograd_split_k(shape, splitk):
         out, _ = _lib.op_conv2d(x, w, b, 1, 1, 1, t | (splitk << 8))
         err = (out - ref).abs().max().item() / ref.abs().max().item()
         assert err <= (1e-4 if "wino4" in name else 2e-5), f"tile {name} split-K {splitk}: {err:.3g}"
+        # round 4: the same split reducing itself (split code 64 + S: write-through slabs, a ticket per output region, the last K slice
+        # sums the slabs in slice order) - the same bits as slab + reduce launch; three runs: whoever arrives last, the same bits
+        for _ in range(3):
+            fused, _ = _lib.op_conv2d(x, w, b, 1, 1, 1, t | ((64 + splitk) << 8))
+            assert torch.equal(fused, out), f"tile {name} self-reducing split-K {splitk}"
+
+
+@pytest.mark.parametrize("shape,splitk", [((1, 16, 16, 1152, 192, 1, 1, 0), 8), ((1, 8, 8, 1288, 4096, 1, 1, 0), 4), ((1, 16, 16, 1280, 320, 2, 2, 0), 16),
+                                          ((2, 10, 20, 1280, 126, 1, 1, 0), 8), ((1, 16, 16, 1344, 640, 3, 1, 1), 12)])
+def test_implicit_gemm_self_reducing_split_k(shape, splitk):
+    """conv_igemm_kernel with split code 64 + S against slab + reduce launch (same bits) and torch: deep-K 1x1, a transposed-conv-shaped
+    GEMM, the k2s2 descriptor conv, a width that is not a multiple of 4 (element-wise slab path), a 3x3 decoder conv at batch 1."""
+    lib = _lib.load()
+    B, H, W, Cin, Cout, K, stride, pad = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape) + splitk)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, K, K, device="cuda", generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    ref = ref_conv(x, w, b, stride, pad, 2)
+    for name in ("conv_igemm_64x32_m16", "conv_igemm_64x64_m32_s1", "conv_igemm_128x128_m16"):
+        t = _tile_id(name)
+        out, _ = _lib.op_conv2d(x, w, b, stride, pad, 2, t | (splitk << 8))
+        err = (out - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-5, f"{name}: {err:.3g}"
+        for _ in range(3):
+            fused, _ = _lib.op_conv2d(x, w, b, stride, pad, 2, t | ((64 + splitk) << 8))
+            assert torch.equal(fused, out), name
 
 
 def test_winograd_tail_split():
@@ -204,3 +231,39 @@ def test_conv2d_rejects_bad_geometry():
     w = torch.randn(4, 8, 5, 5, device="cuda")
     with pytest.raises(_lib.CcvpeError):
         _lib.op_conv2d(x, w, pad=2)       # 25 taps: outside the kernel's tap table
+
+
+def _tile_id(name):
+    lib = _lib.load()
+    for t in range(1, lib.ccvpe_op_num_tiles() + 1):
+        if lib.ccvpe_op_tile_name(t).decode() == name:
+            return t
+    raise KeyError(name)
+
+
+PROJL_SHAPES = [
+    # B, H, W, Cin, Cout, K, stride   (1x1 / k2s2, pad 0): the latency form of kernels_proj.hip
+    (1, 16, 16, 1152, 192, 1, 1),     # block 12 project (gate-less through this hook): 72 steps -> 4-5 per wave
+    (1, 5, 8, 1152, 320, 1, 1),       # Oxford's 40-row map: ragged row tile
+    (2, 10, 20, 1280, 126, 1, 1),     # ground descriptor heads: N not a multiple of 16
+    (1, 8, 8, 1288, 4096, 1, 1),      # loc6 transposed conv as its 1x1 GEMM: K not a multiple of 16 (81 steps: two groups per wave)
+    (1, 16, 16, 1280, 1280, 2, 2),    # aerial descriptor map: four taps, 320 steps (ten per group)
+    (3, 8, 8, 480, 80, 1, 1),         # 30 steps: waves without work
+]
+
+
+@pytest.mark.parametrize("shape", PROJL_SHAPES)
+def test_latency_form_deep_k_gemm_matches_torch(shape):
+    """conv_proj_lat_kernel through ccvpe_op_conv2d: sixteen waves split K, partial sums meet in LDS in wave order."""
+    B, H, W, Cin, Cout, K, stride = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, K, K, device="cuda", generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    ref = ref_conv(x, w, b, stride, 0, 0)
+    for name in ("conv_projl_1", "conv_projl_2", "conv_projl_4"):
+        out, _ = _lib.op_conv2d(x, w, b, stride, 0, 0, _tile_id(name))
+        err = (out - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-5, f"{name}: {err:.3g}"
+        again, _ = _lib.op_conv2d(x, w, b, stride, 0, 0, _tile_id(name))
+        assert torch.equal(out, again)
