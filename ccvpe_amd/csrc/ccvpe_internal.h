@@ -101,6 +101,15 @@ static int conv_out(int n, int k, int s) {
 }
 static int se_squeeze(int cin) { return std::max(1, (int)(cin * 0.25)); }   // model.py:79
 static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+// Width the transposed conv of a decoder level occupies in its concat buffer (round 4).  Channel-slice writes into the buffers are slow
+// when a pixel's piece is not a whole number of 64-byte lines (tools/ubench_strided_write.py: 40 of 56 channels 3.4 TB/s against 5.3
+// dense): the localisation decoder's level 2 (40 + 16 channels) is therefore laid out as [40 | 8 zero | 16] - 64 channels, pieces of
+// 192 and 64 bytes; the transposed conv has eight zero output columns (it writes the zeros), conv2.0 eight zero input columns.
+// CCVPE_PAD_CONCAT=0: the reference's widths.  Every other level of every variant already ends on a line.
+static int deconv_width(const DecLevel& l) {
+    static const bool pad = !(getenv("CCVPE_PAD_CONCAT") && std::atoi(getenv("CCVPE_PAD_CONCAT")) == 0);
+    return (pad && l.skip > 0 && (l.dout * 4) % 64 != 0) ? round_up(l.dout, 16) : l.dout;
+}
 
 // ------------------------------------------------------------------------------------------------
 // weights

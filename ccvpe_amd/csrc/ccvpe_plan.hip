@@ -258,7 +258,7 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
             size_t best = 0;
             for (int j = 0; j < 5; ++j) {
                 const size_t hout = (size_t)16 << j, mbl = (size_t)B * (hout / 16) * (hout / 16);
-                for (int cin : {lv[j].dout + lv[j].skip, lv[j].mid}) {
+                for (int cin : {deconv_width(lv[j]) + lv[j].skip, lv[j].mid}) {
                     const size_t f = mbl * ((cin + 15) / 16) * 9216;
                     if (f <= Plan::WINO_V_FLOATS) best = std::max(best, f);
                 }
@@ -304,8 +304,8 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
     for (int j = 0; j < 6; ++j) {
         const int hw_in = 8 << j;
         loc_in[j] = pl.alloc(B, hw_in, hw_in, 8 + vs.match_ch[j]);
-        loc_cat[j] = pl.alloc(B, hw_in * 2, hw_in * 2, vs.loc[j].dout + vs.loc[j].skip);
-        ori_cat[j] = pl.alloc(B, hw_in * 2, hw_in * 2, vs.ori[j].dout + vs.ori[j].skip);
+        loc_cat[j] = pl.alloc(B, hw_in * 2, hw_in * 2, deconv_width(vs.loc[j]) + vs.loc[j].skip);
+        ori_cat[j] = pl.alloc(B, hw_in * 2, hw_in * 2, deconv_width(vs.ori[j]) + vs.ori[j].skip);
         // bf16x3 mode: tensors consumed only by convolutions live as pre-split bf16 planes (same bytes), so the
         // consumers' K loops carry no fp32->bf16 conversion; level 1 (j == 5) feeds the fp32 tail and stays fp32
         if (h->cfg.reserved[0] == 1 && j < 5 && !getenv("CCVPE_NO_SPLIT_PLANES")) { loc_cat[j].split = true; ori_cat[j].split = true; }
@@ -318,8 +318,8 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
     TapDst td[5];
     for (int t = 0; t < 5; ++t) {
         td[t].n = 2;
-        td[t].t[0] = loc_cat[t]; td[t].coff[0] = vs.loc[t].dout;
-        td[t].t[1] = ori_cat[t]; td[t].coff[1] = vs.ori[t].dout;
+        td[t].t[0] = loc_cat[t]; td[t].coff[0] = deconv_width(vs.loc[t]);
+        td[t].t[1] = ori_cat[t]; td[t].coff[1] = deconv_width(vs.ori[t]);
     }
     size_t coff[6];
     cache_layout(vs, B, coff);
@@ -328,7 +328,7 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
     } else {
         for (int t = 0; t < 5; ++t) {   // cached encoder taps -> skip halves of the decoder concat buffers
             Tensor lc = loc_cat[t], oc = ori_cat[t];
-            const int lcoff = vs.loc[t].dout, ocoff = vs.ori[t].dout;
+            const int lcoff = deconv_width(vs.loc[t]), ocoff = deconv_width(vs.ori[t]);
             const size_t src_off = coff[t + 1];
             const int C = TAP_C[t];
             const long long P = (long long)B * TAP_HW[t];
@@ -390,7 +390,7 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
         const DecLevel& l = lv[j];
         {
             const PackedConv* pc = &dw.deconv[j];
-            const int cout = l.dout;
+            const int cout = deconv_width(l);   // (columns past l.dout: zero weights and biases, written as zeros)
             pl.add_conv(tag + ".deconv", {din, cat}, B * hin * hin, pc->N, pc->Kpad, [=](const Ctx& c, int tile) {
                 ConvParams p = conv_params(*pc, c.ptr(din), din.C, B, hin, hin, hin, hin, 1, 0, 0, ACT_NONE);
                 p.mode = MODE_DECONV; p.deconv_cout = cout;
@@ -461,8 +461,8 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
     // critical path).  CCVPE_MATCH_PREP_EARLY=0: inside each level's launch as before.
     const bool prep_early = !(getenv("CCVPE_MATCH_PREP_EARLY") && std::atoi(getenv("CCVPE_MATCH_PREP_EARLY")) == 0);
     size_t first_match_op = (size_t)-1;
-    std::vector<std::function<void(const Ctx&)>> prep_fns;
-    std::vector<std::vector<Tensor>> prep_uses;
+    std::vector<std::function<MatchParams(const Ctx&)>> prep_fills;
+    std::vector<Tensor> prep_uses;
     for (int k = 0; k < 6; ++k) {   // matching level k+1 feeds decoder level 6-k
         MatchParams mp{};
         const int hw = (8 << k) * (8 << k);
@@ -505,8 +505,9 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
         };
         if (first_match_op == (size_t)-1) first_match_op = pl.ops.size();
         if (prep_early) {
-            prep_fns.push_back([=](const Ctx& c) { launch_match_prep(fill(c), c.stream); });
-            prep_uses.push_back({desc, ggs});
+            prep_fills.push_back(fill);
+            if (prep_uses.empty()) prep_uses.push_back(desc);
+            prep_uses.push_back(ggs);
         }
         pl.add("match" + std::to_string(k + 1), uses, [=](const Ctx& c) { launch_match(fill(c), c.stream); },
                4.0 * B * hw * (double)R * L[k], 4.0 * B * hw * (2.0 * C + R + 8));
@@ -516,9 +517,14 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
         if (k < 5) { pl.taps["loc_level" + std::to_string(6 - k)] = {o, 0, o.C}; x = o; }
         else loc_mid = o;
     }
-    if (!prep_fns.empty()) {   // the preparation launches go in front of the first matching level
+    if (!prep_fills.empty()) {   // the preparation of all levels: ONE launch (kernels_match.hip), in front of the first matching level
         const size_t n0 = pl.ops.size();
-        for (size_t i = 0; i < prep_fns.size(); ++i) pl.add("match" + std::to_string(i + 1) + ".prep", prep_uses[i], prep_fns[i], 0.0, 0.0);
+        pl.add("match.prep", prep_uses, [prep_fills](const Ctx& c) {
+            MatchParams ps[6];
+            const int n = (int)std::min<size_t>(prep_fills.size(), 6);
+            for (int i = 0; i < n; ++i) ps[i] = prep_fills[i](c);
+            launch_match_prep_all(ps, n, c.stream);
+        }, 0.0, 0.0);
         std::rotate(pl.ops.begin() + first_match_op, pl.ops.begin() + n0, pl.ops.end());
     }
     if (!h->fuse_level1) {

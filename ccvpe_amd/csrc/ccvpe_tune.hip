@@ -152,6 +152,7 @@ int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
             // the persistent Winograd grids also try odd split factors: 160 work items on 256 resident workgroups (conv6.0) are
             // 3 rounds of quarter items with split 4 but 2 rounds of thirds with split 3
             static const int SPLITS[] = {1, 255, 2, 3, 4, 5, 6, 8, 12, 16};   // 255: F(4x4) tail split (kernels_wino4.hip); before the rest, whose limits end the loop
+            // (20 / 24 / 32 slices were timed for the batch-1 decoder layers in round 4 - two workgroups per CU instead of one: never picked)
             for (int split : SPLITS) {
                 if (split > 1 && no_split) break;
                 if (split == 255 && (!conv_igemm_tile_is_wino4(t) || conv_igemm_tile_is_wino4x(t))) continue;

@@ -71,7 +71,7 @@ static int upload(ccvpe_handle_s* h, const std::vector<float>& v, float** out) {
 
 // Environment switches the packer branches on: ONE list, read by pack_conv's callers' cache key (ccvpe_pack_switches) - a packed-weight
 // file written under one setting must never be loaded under another (ccvpe_load_packed restores every descriptor from the file).
-static const char* const PACK_SWITCHES[] = {"CCVPE_NO_PROJ", "CCVPE_WINO4_MIN_N", "CCVPE_NO_WINO4", "CCVPE_NO_WINO4X"};
+static const char* const PACK_SWITCHES[] = {"CCVPE_NO_PROJ", "CCVPE_WINO4_MIN_N", "CCVPE_NO_WINO4", "CCVPE_NO_WINO4X", "CCVPE_PAD_CONCAT"};
 extern "C" const char* ccvpe_pack_switches(void) {
     static thread_local std::string s;
     s.clear();
@@ -230,7 +230,7 @@ static int build_decoder(ccvpe_handle_s* h, DecoderW& d, const DecLevel* lv, con
         {   // ConvTranspose2d weight [cin][cout][2][2] -> rows n = (dy*2+dx)*cout + o
             const auto& w = h->host["deconv" + n + sfx + ".weight"];
             const auto& b = h->host["deconv" + n + sfx + ".bias"];
-            const int cin = lv[j].din, cout = lv[j].dout;
+            const int cin = lv[j].din, cout = lv[j].dout, cw = deconv_width(lv[j]);   // cw >= cout: zero columns (ccvpe_internal.h)
             int nscore = 0;
             if (every_level_scored) nscore = 1;
             else if (j == 0) nscore = nscore_l6;
@@ -238,10 +238,10 @@ static int build_decoder(ccvpe_handle_s* h, DecoderW& d, const DecLevel* lv, con
             const int cinp = spad + (cin - nscore);
             std::vector<int> cmap(cin);
             for (int c = 0; c < cin; ++c) cmap[c] = c < nscore ? c : c - nscore + spad;
-            std::vector<float> bias(4 * cout);
-            for (int qd = 0; qd < 4; ++qd) for (int o = 0; o < cout; ++o) bias[qd * cout + o] = b[o];
-            if ((rc = pack_conv(h, d.deconv[j], 4 * cout, 1, cin, cinp, cmap,
-                                [&](int nn, int, int c) { int qd = nn / cout, o = nn % cout; return w[((size_t)c * cout + o) * 4 + qd]; },
+            std::vector<float> bias(4 * cw, 0.f);
+            for (int qd = 0; qd < 4; ++qd) for (int o = 0; o < cout; ++o) bias[qd * cw + o] = b[o];
+            if ((rc = pack_conv(h, d.deconv[j], 4 * cw, 1, cin, cinp, cmap,
+                                [&](int nn, int, int c) { int qd = nn / cw, o = nn % cw; return o < cout ? w[((size_t)c * cout + o) * 4 + qd] : 0.f; },
                                 bias, 1, 1))) return rc;
         }
         if (j == 5) {   // dedicated layouts for the fused last level
@@ -270,9 +270,14 @@ static int build_decoder(ccvpe_handle_s* h, DecoderW& d, const DecLevel* lv, con
         }
         {
             const auto& w = h->host["conv" + n + sfx + ".0.weight"];
-            const int cin = lv[j].dout + lv[j].skip, cout = lv[j].mid;
-            if ((rc = pack_conv(h, d.conva[j], cout, 9, cin, cin, identity_map(cin),
-                                [&](int nn, int t, int c) { return w[((size_t)nn * cin + c) * 9 + t]; },
+            const int dout = lv[j].dout, cw = deconv_width(lv[j]);
+            const int cin = dout + lv[j].skip, cinw = cw + lv[j].skip, cout = lv[j].mid;   // cinw: with the zero columns behind the transposed conv's channels
+            if ((rc = pack_conv(h, d.conva[j], cout, 9, cinw, cinw, identity_map(cinw),
+                                [&](int nn, int t, int c) {
+                                    if (c >= dout && c < cw) return 0.f;
+                                    const int cr = c < dout ? c : c - (cw - dout);
+                                    return w[((size_t)nn * cin + cr) * 9 + t];
+                                },
                                 h->host["conv" + n + sfx + ".0.bias"], 3, 3))) return rc;
         }
         const auto& w2 = h->host["conv" + n + sfx + ".2.weight"];

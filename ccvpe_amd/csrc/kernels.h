@@ -300,6 +300,7 @@ void launch_match(const MatchParams& p, hipStream_t s);
 // The preparation launch alone (rolled descriptor / Gm, Mk into gg_scratch): it depends on the ground descriptor only, so a plan may issue it
 // long before the aerial features exist.  Same form decision as launch_match when given the same parameters; no launch for the LDS form.
 void launch_match_prep(const MatchParams& p, hipStream_t s);
+void launch_match_prep_all(const MatchParams* ps, int n, hipStream_t s);   // the preparation of up to six levels in one launch
 int match_pixels_per_block(int HW, int C);
 size_t match_scratch_floats(int C);   // per-sample floats of MatchParams::gg_scratch
 

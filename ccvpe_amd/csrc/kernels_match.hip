@@ -125,9 +125,8 @@ __global__ __launch_bounds__(256) void match_kernel(const MatchParams p) {
 // wave-uniform run (scalar / broadcast loads).  When L < C the window norm uses the doubled 0/1 mask the same
 // way; when L == C it is the roll-invariant full norm.  x is read once, no LDS, no per-pixel modulo.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void match_prep_kernel(const MatchParams p, float* gg) {
+__device__ __forceinline__ void match_prep_body(const MatchParams& p, float* gg, float* red) {
     // gg[b] = [ gpad | gpad | mask | mask | ||g|| ]  (4C + 1 floats per sample)
-    __shared__ float red[4];
     const int b = blockIdx.x, C = p.C, L = p.L;
     float* o = gg + (size_t)b * (4 * C + 4);
     float gsq = 0.f;
@@ -143,6 +142,10 @@ __global__ __launch_bounds__(256) void match_prep_kernel(const MatchParams p, fl
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gsq;
     __syncthreads();
     if (threadIdx.x == 0) o[4 * C] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void match_prep_kernel(const MatchParams p, float* gg) {
+    __shared__ float red[4];
+    match_prep_body(p, gg, red);
 }
 
 template <int C>
@@ -202,9 +205,8 @@ __global__ __launch_bounds__(256) void match_small_kernel(const MatchParams p, c
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void match_mfma_prep_kernel(const MatchParams p, float* gm) {
+__device__ __forceinline__ void match_mfma_prep_body(const MatchParams& p, float* gm, float* red) {
     // gm[b]: [C/16 chunks][2 tiles][64 lanes][4] for G, then the same for the mask, then ||g||
-    __shared__ float red[4];
     const int b = blockIdx.x, C = p.C, L = p.L;
     const size_t per = (size_t)C * 32;
     float* G = gm + (size_t)b * (2 * per + 4);
@@ -232,6 +234,20 @@ __global__ __launch_bounds__(256) void match_mfma_prep_kernel(const MatchParams 
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gsq;
     __syncthreads();
     if (threadIdx.x == 0) G[2 * per] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void match_mfma_prep_kernel(const MatchParams p, float* gm) {
+    __shared__ float red[4];
+    match_mfma_prep_body(p, gm, red);
+}
+// The preparation of all matching levels in ONE launch (round 4): they depend on the ground descriptor only, and as six launches of a
+// few microseconds each they were 47 us of the ground stream's issue order at batch 1.  grid (B, 8, levels); form[z]: 0 nothing to
+// prepare (LDS form), 1 rolled descriptor of the register form, 2 Gm / Mk of the MFMA form.
+struct MatchPrepAll { MatchParams p[6]; int form[6]; };
+__global__ __launch_bounds__(256) void match_prep_all_kernel(const MatchPrepAll a) {
+    __shared__ float red[4];
+    const int z = blockIdx.z;
+    if (a.form[z] == 2) match_mfma_prep_body(a.p[z], a.p[z].gg_scratch, red);
+    else if (a.form[z] == 1 && blockIdx.y == 0) match_prep_body(a.p[z], a.p[z].gg_scratch, red);
 }
 
 __global__ __launch_bounds__(256) void match_mfma_kernel(const MatchParams p, const float* __restrict__ gm) {
@@ -360,6 +376,17 @@ static bool match_use_mfma(const MatchParams& p) {
 void launch_match_prep(const MatchParams& p, hipStream_t s) {
     if (match_use_mfma(p)) hipLaunchKernelGGL(match_mfma_prep_kernel, dim3(p.B, 8), dim3(256), 0, s, p, p.gg_scratch);
     else if (p.gg_scratch && match_small_supported(p)) hipLaunchKernelGGL(match_prep_kernel, dim3(p.B), dim3(256), 0, s, p, p.gg_scratch);
+}
+
+void launch_match_prep_all(const MatchParams* ps, int n, hipStream_t s) {
+    MatchPrepAll a{};
+    bool any = false;
+    for (int i = 0; i < n && i < 6; ++i) {
+        a.p[i] = ps[i];
+        a.form[i] = match_use_mfma(ps[i]) ? 2 : (ps[i].gg_scratch && match_small_supported(ps[i])) ? 1 : 0;
+        any = any || a.form[i] != 0;
+    }
+    if (any) hipLaunchKernelGGL(match_prep_all_kernel, dim3(ps[0].B, 8, std::min(n, 6)), dim3(256), 0, s, a);
 }
 
 void launch_match(const MatchParams& p, hipStream_t s) {
