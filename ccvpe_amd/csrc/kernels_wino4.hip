@@ -118,7 +118,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int r_px0 = tid >> 2;       // pixel of item 0; item i is pixel r_px0 + (NT / 4) i
 #define CCVPE_W4_ROFF(b_, by_, bx_, live_)                                                               \
     _Pragma("unroll") for (int i = 0; i < RAW_ITEMS; ++i) {                                              \
-        const int j = tid + i * NT;                                                                      \
+        int j = tid + i * NT;                                                                            \
+        asm volatile("" : "+v"(j));   /* recomputed per item: hoisted, the six (row, column) pairs of a thread lived in scratch (12 spills - and a kernel that touches scratch starts ~5 us later: tools/ubench_scratch.hip) */ \
         const int px = j >> 2, q = j & 3;                                                                \
         const int py = px / 18, pxx = px - py * 18;                                                      \
         const int y = (by_) * 16 - 1 + py, x = (bx_) * 16 - 1 + pxx;                                     \

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int r_px0 = tid >> 2;
 #define CCVPE_X4_ROFF(b_, by_, bx_, live_)                                                               \
     _Pragma("unroll") for (int i = 0; i < RAW_ITEMS; ++i) {                                              \
-        const int j = tid + i * NT;                                                                      \
+        int j = tid + i * NT;                                                                            \
+        asm volatile("" : "+v"(j));   /* recomputed per item, not hoisted into scratch (kernels_wino4.hip) */ \
         const int px = j >> 2, qq = j & 3;                                                               \
         const int py = px / 18, pxx = px - py * 18;                                                      \
         const int y = (by_) * 16 - 1 + py, x = (bx_) * 16 - 1 + pxx;                                     \

@@ -101,3 +101,26 @@ def test_no_vector_write_lands_on_the_data_of_a_wide_store_in_the_next_slot():
             if s:
                 pending = (int(s.group(2)), int(s.group(3)), t)
     assert not offenders, "vector write onto the data registers of the preceding wide store:\n" + "\n".join(offenders[:30])
+
+
+SCRATCH = re.compile(r"^\s*\.private_segment_fixed_size:\s+(\d+)")
+NAME = re.compile(r"^\s*\.name:\s+(\S+)")
+
+
+def test_no_kernel_uses_scratch():
+    """Round 4: a kernel that touches scratch (register spills, a non-inlined call) starts ~5 us later than one that does not
+    (tools/ubench_scratch.hip: 3.3 -> 7.9 us per launch of 256 workgroups, more with larger grids) - a fixed price on every launch of
+    a batch-1 frame, and three of the Winograd kernels had paid it since round 2 for twelve hoisted index registers.  No kernel of
+    the library may have a private segment."""
+    offenders = []
+    for src, r in _all_asm():
+        assert r.returncode == 0, f"{src}: {r.stderr[-2000:]}"
+        name = "?"
+        for line in r.stdout.splitlines():
+            m = NAME.match(line)
+            if m:
+                name = m.group(1)
+            s = SCRATCH.match(line)
+            if s and int(s.group(1)) > 0:
+                offenders.append(f"{src}: {name}: {s.group(1)} bytes of scratch")
+    assert not offenders, "\n".join(offenders[:20])
