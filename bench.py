@@ -21,7 +21,7 @@ Besides the contract line rank 0 prints (N = 1 only for everything but `roofline
                  (tile padding included; Winograd F(2x2,3x3) issues 16 products per 2x2 tile) over its time and
                  over the fp32-MFMA peak - always <= 1; `algorithmic_tflops` = the layer's direct-convolution FLOPs
                   over the same time; `end_to_end` = 56.37 GFLOP/query x queries/s over the peak.
-  batch1         the same model at batch 1 (latency mode, hipGraph replay): queries/s, p50 / p99 ms
+  batch1         the same model at batch 1 (latency mode): queries/s, p50 / p99 ms of a synchronised step, kernel launches per frame
   configs        BASELINE.json configs 3-5: VIGOR FoV 108 / noise 72 (batch 32), KITTI (batch 32), Oxford streaming
                  (batch 1, p50 / p99, FPS against the reference README's 14 FPS)
   alt_precision  the opt-in bf16x3 mode (never the headline)
@@ -320,7 +320,14 @@ def main() -> int:
             st()
         torch.cuda.synchronize(dev)
         thr = n * gg.shape[0] / (time.perf_counter() - t)
-        return {"queries_per_s": thr, "p50_ms": lat[n // 2], "p99_ms": lat[min(n - 1, int(n * 0.99))], "steps": n, "batch": gg.shape[0]}
+        from ccvpe_amd import _lib as _cl2
+        c0 = _cl2.load().ccvpe_launch_count()
+        st()
+        torch.cuda.synchronize(dev)
+        launches = int(_cl2.load().ccvpe_launch_count() - c0)
+        return {"queries_per_s": thr, "p50_ms": lat[n // 2], "p99_ms": lat[min(n - 1, int(n * 0.99))], "steps": n, "batch": gg.shape[0],
+                "launches_per_frame": launches,
+                "launches_note": "kernel launches the library issues for one step (forward + postprocess; ccvpe_launch_count), eager issue interleaved over two streams"}
 
     def throughput_run(name, batch, n=30, warm=5):
         v, k, f = WORKLOADS[name]
@@ -461,7 +468,7 @@ def main() -> int:
         if extras and not args.no_extra:
             # BASELINE.json metric asks batch 1 AND 32; BASELINE.md section 5 lists configs 3-5
             line["batch1"] = latency_run(model, grd[:1].contiguous(), sat[:1].contiguous())
-            line["batch1"]["note"] = "same model, batch 1, hipGraph replay; latency = one synchronised step (forward + post-processing)"
+            line["batch1"]["note"] = "same model, batch 1 (latency mode: eager launches interleaved over two streams; CCVPE_GRAPH=1 replays a hipGraph instead); latency = one synchronised step (forward + post-processing)"
             if variant.startswith("vigor") and fov == 360.0:
                 line["pipeline"] = pipeline_run(model)
         del model

@@ -30,6 +30,7 @@ class Pose(C.Structure):
 SYMBOLS = [
     ("ccvpe_last_error", C.c_char_p, []),
     ("ccvpe_version", C.c_char_p, []),
+    ("ccvpe_launch_count", C.c_uint64, []),
     ("ccvpe_create", C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     ("ccvpe_destroy", C.c_int, [C.c_void_p]),
     ("ccvpe_set_weight", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),

@@ -9,6 +9,7 @@
 // ------------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------------
+namespace ccvpe { thread_local unsigned long long g_launches = 0; }
 static thread_local std::string g_err_storage;
 std::string& ccvpe_err() { return g_err_storage; }
 int ccvpe_fail(int code, const char* fmt, ...) {
@@ -37,6 +38,7 @@ extern "C" {
 
 const char* ccvpe_last_error(void) { return ccvpe_err().c_str(); }
 const char* ccvpe_version(void) { return "ccvpe-hip 0.1 (gfx950, fp32 MFMA)"; }
+uint64_t ccvpe_launch_count(void) { return ccvpe::g_launches; }
 
 int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out) {
     if (!cfg || !out) return ccvpe_fail(CCVPE_EINVAL, "null argument");
@@ -515,7 +517,7 @@ int ccvpe_debug_dump_plan(ccvpe_handle h, const char* path) {
     for (size_t id = 0; id < n; ++id) {
         if (pl->size[id] == 0) continue;
         const int blocks = (int)std::min<size_t>((pl->size[id] + 255) / 256, 2048);
-        hipLaunchKernelGGL(checksum_kernel, dim3(blocks), dim3(256), 0, nullptr, reinterpret_cast<const uint32_t*>(h->arena + pl->off[id]), pl->size[id], d + id);
+        CCVPE_LAUNCH(checksum_kernel, dim3(blocks), dim3(256), 0, nullptr, reinterpret_cast<const uint32_t*>(h->arena + pl->off[id]), pl->size[id], d + id);
     }
     std::vector<unsigned long long> sums(n);
     hipError_t e = hipMemcpy(sums.data(), d, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -543,7 +545,7 @@ int ccvpe_debug_dump_plan(ccvpe_handle h, const char* path) {
                 if (hipMalloc((void**)&dd, sizeof(v)) == hipSuccess) {
                     (void)hipMemset(dd, 0, sizeof(v));
                     const int blocks = (int)std::min<size_t>((pl->size[e.first] + 255) / 256, 2048);
-                    hipLaunchKernelGGL(checksum_kernel, dim3(blocks), dim3(256), 0, nullptr, reinterpret_cast<const uint32_t*>(h->snap[which] + e.second), pl->size[e.first], dd);
+                    CCVPE_LAUNCH(checksum_kernel, dim3(blocks), dim3(256), 0, nullptr, reinterpret_cast<const uint32_t*>(h->snap[which] + e.second), pl->size[e.first], dd);
                     (void)hipMemcpy(&v, dd, sizeof(v), hipMemcpyDeviceToHost);
                     (void)hipFree(dd);
                 }

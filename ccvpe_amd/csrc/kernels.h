@@ -8,6 +8,11 @@
 
 namespace ccvpe {
 
+// Every kernel launch of the library goes through this macro: ccvpe_launch_count() (include/ccvpe.h) lets a caller count the launches of
+// a forward call - the batch-1 latency record of bench.py reports launches per frame.
+extern thread_local unsigned long long g_launches;
+#define CCVPE_LAUNCH(...) do { ++::ccvpe::g_launches; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: the launchers raise it lazily, once per
 // (kernel instantiation, device) - a process may hold handles on several devices.  `state` is a function-local static array
 // (one slot per device ordinal); a failing hipFuncSetAttribute leaves the slot unset, the launch that follows then fails and

@@ -169,13 +169,13 @@ void launch_stem(const StemParams& p, hipStream_t s) {
     static const bool pixel_form = getenv("CCVPE_STEM_TILE") && std::atoi(getenv("CCVPE_STEM_TILE")) == 0;   // A/B switch
     if (!pixel_form) {
         const int tiles = p.B * ((p.OW + ST_TW - 1) / ST_TW) * ((p.OH + ST_TH - 1) / ST_TH);
-        hipLaunchKernelGGL(stem_tile_kernel, dim3(std::min(tiles, 256 * 6)), dim3(256), 0, s, p);
+        CCVPE_LAUNCH(stem_tile_kernel, dim3(std::min(tiles, 256 * 6)), dim3(256), 0, s, p);
         return;
     }
     long long total = (long long)p.B * p.OH * p.OW * 8;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(stem_kernel, dim3(blocks), dim3(256), 0, s, p);
+    CCVPE_LAUNCH(stem_kernel, dim3(blocks), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -394,7 +394,7 @@ void launch_stem_dw(const StemDwParams& q, hipStream_t s) {
     const size_t lds = (size_t)(((3 * SD_PH * SD_PITCH + 3) & ~3) + SD_SH * SD_SW * 32 + 4 * 32 + 9 * 32 + 27 * 32) * sizeof(float);
     static LdsAttr attr;
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(stem_dw_kernel), lds);
-    hipLaunchKernelGGL(stem_dw_kernel, dim3(std::min(tiles, 512)), dim3(256), lds, s, q);
+    CCVPE_LAUNCH(stem_dw_kernel, dim3(std::min(tiles, 512)), dim3(256), lds, s, q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -509,10 +509,10 @@ int depthwise_strip_lanes(int B, int OH, int OW, int C, int k, int stride) {
 void launch_depthwise(const DwParams& p, hipStream_t s) {
     long long total = (long long)p.B * p.S * (p.C / 4);
     int blocks = (int)((total + 255) / 256);
-    if (p.k == 3 && p.stride == 1) hipLaunchKernelGGL((depthwise_kernel<3, 1, DW_TX, DW_TY>), dim3(blocks), dim3(256), 0, s, p);
-    else if (p.k == 3 && p.stride == 2) hipLaunchKernelGGL((depthwise_kernel<3, 2, DW_TX, DW_TY>), dim3(blocks), dim3(256), 0, s, p);
-    else if (p.k == 5 && p.stride == 1) hipLaunchKernelGGL((depthwise_kernel<5, 1, DW_TX, DW_TY>), dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((depthwise_kernel<5, 2, DW_TX, DW_TY>), dim3(blocks), dim3(256), 0, s, p);
+    if (p.k == 3 && p.stride == 1) CCVPE_LAUNCH((depthwise_kernel<3, 1, DW_TX, DW_TY>), dim3(blocks), dim3(256), 0, s, p);
+    else if (p.k == 3 && p.stride == 2) CCVPE_LAUNCH((depthwise_kernel<3, 2, DW_TX, DW_TY>), dim3(blocks), dim3(256), 0, s, p);
+    else if (p.k == 5 && p.stride == 1) CCVPE_LAUNCH((depthwise_kernel<5, 1, DW_TX, DW_TY>), dim3(blocks), dim3(256), 0, s, p);
+    else CCVPE_LAUNCH((depthwise_kernel<5, 2, DW_TX, DW_TY>), dim3(blocks), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -578,13 +578,13 @@ void launch_se(const SeParams& p, hipStream_t s) {
     if (p.S <= 16) {   // the image-resident front kernels leave 1-16 partial rows per sample: the squeeze kernel sums them itself
         SeParams q = p;
         q.SC = p.S;
-        hipLaunchKernelGGL(se_squeeze_kernel, dim3(p.SQ, p.B), dim3(256), 0, s, q, (const float*)p.pool_partial, p.sq);
-        hipLaunchKernelGGL(se_excite_kernel, dim3((p.C + 255) / 256, p.B), dim3(256), 0, s, p, (const float*)p.sq);
+        CCVPE_LAUNCH(se_squeeze_kernel, dim3(p.SQ, p.B), dim3(256), 0, s, q, (const float*)p.pool_partial, p.sq);
+        CCVPE_LAUNCH(se_excite_kernel, dim3((p.C + 255) / 256, p.B), dim3(256), 0, s, p, (const float*)p.sq);
         return;
     }
-    hipLaunchKernelGGL(se_pool_kernel, dim3((p.C + 63) / 64, p.B, p.SC), dim3(256), 0, s, p, p.pooled);
-    hipLaunchKernelGGL(se_squeeze_kernel, dim3(p.SQ, p.B), dim3(256), 0, s, p, (const float*)p.pooled, p.sq);
-    hipLaunchKernelGGL(se_excite_kernel, dim3((p.C + 255) / 256, p.B), dim3(256), 0, s, p, (const float*)p.sq);
+    CCVPE_LAUNCH(se_pool_kernel, dim3((p.C + 63) / 64, p.B, p.SC), dim3(256), 0, s, p, p.pooled);
+    CCVPE_LAUNCH(se_squeeze_kernel, dim3(p.SQ, p.B), dim3(256), 0, s, p, (const float*)p.pooled, p.sq);
+    CCVPE_LAUNCH(se_excite_kernel, dim3((p.C + 255) / 256, p.B), dim3(256), 0, s, p, (const float*)p.sq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void grd_desc_kernel(const GrdDescParams p) {
 }
 
 void launch_grd_desc(const GrdDescParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(grd_desc_kernel, dim3((p.Ltot + 255) / 256, p.B), dim3(256), 0, s, p);
+    CCVPE_LAUNCH(grd_desc_kernel, dim3((p.Ltot + 255) / 256, p.B), dim3(256), 0, s, p);
 }
 
 }  // namespace ccvpe

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
 void launch_splitk_reduce(const ConvParams& p, hipStream_t s) {
     const long long total = (long long)p.M * ((p.N + 3) / 4);
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+    CCVPE_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
 }
 
 template <int BM, int BN, int WGM, int WGN, int MT, bool GATE, int NS>
@@ -310,9 +310,9 @@ static void launch_cfg2(const ConvParams& p, hipStream_t s) {
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.splitk > 1 ? p.splitk : 1);
     if (p.splitk <= 1 || p.tickets == nullptr || (long long)grid.x * grid.y > CONV_TICKETS) {
-        if (p.split_fused) { ConvParams q = p; q.split_fused = 0; hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, q); if (q.splitk > 1) launch_splitk_reduce(q, s); return; }
+        if (p.split_fused) { ConvParams q = p; q.split_fused = 0; CCVPE_LAUNCH(kern, grid, dim3(256), lds, s, q); if (q.splitk > 1) launch_splitk_reduce(q, s); return; }
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    CCVPE_LAUNCH(kern, grid, dim3(256), lds, s, p);
     if (p.splitk > 1 && !p.split_fused) launch_splitk_reduce(p, s);
 }
 

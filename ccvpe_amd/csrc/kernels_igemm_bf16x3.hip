@@ -362,7 +362,7 @@ static void launch_b2(const ConvParams& p, hipStream_t s) {
     auto kern = conv_igemm_bf16x3_kernel<BM, BN, WGM, WGN, MT, GATE, SPLIT>;
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.splitk > 1 ? p.splitk : 1);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    CCVPE_LAUNCH(kern, grid, dim3(256), lds, s, p);
     if (p.splitk > 1) launch_splitk_reduce(p, s);
 }
 

@@ -346,11 +346,11 @@ void launch_level1(const Level1Params& p, hipStream_t s) {
     if (p.cout == 1) {
         static LdsAttr attr1;
         ensure_dynamic_lds(attr1, reinterpret_cast<const void*>(level1_kernel<1>), lds);
-        hipLaunchKernelGGL(level1_kernel<1>, grid, dim3(256), lds, s, p);
+        CCVPE_LAUNCH(level1_kernel<1>, grid, dim3(256), lds, s, p);
     } else {
         static LdsAttr attr2;
         ensure_dynamic_lds(attr2, reinterpret_cast<const void*>(level1_kernel<2>), lds);
-        hipLaunchKernelGGL(level1_kernel<2>, grid, dim3(256), lds, s, p);
+        CCVPE_LAUNCH(level1_kernel<2>, grid, dim3(256), lds, s, p);
     }
 #if CCVPE_L1_CLOCK
     if (stamp) {

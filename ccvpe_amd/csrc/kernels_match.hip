@@ -374,8 +374,8 @@ static bool match_use_mfma(const MatchParams& p) {
 }
 
 void launch_match_prep(const MatchParams& p, hipStream_t s) {
-    if (match_use_mfma(p)) hipLaunchKernelGGL(match_mfma_prep_kernel, dim3(p.B, 8), dim3(256), 0, s, p, p.gg_scratch);
-    else if (p.gg_scratch && match_small_supported(p)) hipLaunchKernelGGL(match_prep_kernel, dim3(p.B), dim3(256), 0, s, p, p.gg_scratch);
+    if (match_use_mfma(p)) CCVPE_LAUNCH(match_mfma_prep_kernel, dim3(p.B, 8), dim3(256), 0, s, p, p.gg_scratch);
+    else if (p.gg_scratch && match_small_supported(p)) CCVPE_LAUNCH(match_prep_kernel, dim3(p.B), dim3(256), 0, s, p, p.gg_scratch);
 }
 
 void launch_match_prep_all(const MatchParams* ps, int n, hipStream_t s) {
@@ -386,30 +386,30 @@ void launch_match_prep_all(const MatchParams* ps, int n, hipStream_t s) {
         a.form[i] = match_use_mfma(ps[i]) ? 2 : (ps[i].gg_scratch && match_small_supported(ps[i])) ? 1 : 0;
         any = any || a.form[i] != 0;
     }
-    if (any) hipLaunchKernelGGL(match_prep_all_kernel, dim3(ps[0].B, 8, std::min(n, 6)), dim3(256), 0, s, a);
+    if (any) CCVPE_LAUNCH(match_prep_all_kernel, dim3(ps[0].B, 8, std::min(n, 6)), dim3(256), 0, s, a);
 }
 
 void launch_match(const MatchParams& p, hipStream_t s) {
     if (match_use_mfma(p)) {
-        if (!p.prep_done) hipLaunchKernelGGL(match_mfma_prep_kernel, dim3(p.B, 8), dim3(256), 0, s, p, p.gg_scratch);
+        if (!p.prep_done) CCVPE_LAUNCH(match_mfma_prep_kernel, dim3(p.B, 8), dim3(256), 0, s, p, p.gg_scratch);
         const size_t lds = ((size_t)16 * (p.C + 4) + 4 * 2 * 2 * 256 + 32 * 16) * sizeof(float);
         static LdsAttr attr;
         if (lds > 64 * 1024) ensure_dynamic_lds(attr, reinterpret_cast<const void*>(match_mfma_kernel), lds);
-        hipLaunchKernelGGL(match_mfma_kernel, dim3(p.B * (p.HW >> 4)), dim3(256), lds, s, p, (const float*)p.gg_scratch);
+        CCVPE_LAUNCH(match_mfma_kernel, dim3(p.B * (p.HW >> 4)), dim3(256), lds, s, p, (const float*)p.gg_scratch);
         return;
     }
     if (p.gg_scratch && match_small_supported(p)) {
-        if (!p.prep_done) hipLaunchKernelGGL(match_prep_kernel, dim3(p.B), dim3(256), 0, s, p, p.gg_scratch);
+        if (!p.prep_done) CCVPE_LAUNCH(match_prep_kernel, dim3(p.B), dim3(256), 0, s, p, p.gg_scratch);
         dim3 grid((p.HW + 255) / 256, p.B);
-        if (p.C == 32) hipLaunchKernelGGL(match_small_kernel<32>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
-        else if (p.C == 40) hipLaunchKernelGGL(match_small_kernel<40>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
-        else hipLaunchKernelGGL(match_small_kernel<80>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
+        if (p.C == 32) CCVPE_LAUNCH(match_small_kernel<32>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
+        else if (p.C == 40) CCVPE_LAUNCH(match_small_kernel<40>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
+        else CCVPE_LAUNCH(match_small_kernel<80>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
         return;
     }
     size_t lds = ((size_t)p.P * (p.C + 1) + ((p.L + 3) & ~3) + (size_t)(p.R + 1) * p.P + 4) * sizeof(float);
     static LdsAttr attr;
     if (lds > 64 * 1024) ensure_dynamic_lds(attr, reinterpret_cast<const void*>(match_kernel), lds);
-    hipLaunchKernelGGL(match_kernel, dim3(p.B * (p.HW / p.P)), dim3(256), lds, s, p);
+    CCVPE_LAUNCH(match_kernel, dim3(p.B * (p.HW / p.P)), dim3(256), lds, s, p);
 }
 
 }  // namespace ccvpe

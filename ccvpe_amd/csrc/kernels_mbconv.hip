@@ -344,13 +344,13 @@ static void launch_mb_wave(const MbFrontParams& p, hipStream_t s) {
         static LdsAttr attr4;
         auto kern = mbconv_front_wave_kernel<K, S, TW, TH, KCH, WAVE_NWG>;
         ensure_dynamic_lds(attr4, reinterpret_cast<const void*>(kern), lds);
-        hipLaunchKernelGGL(kern, dim3((tiles + WAVE_NWG - 1) / WAVE_NWG, p.B), dim3(64 * WAVE_NWG), lds, s, p);
+        CCVPE_LAUNCH(kern, dim3((tiles + WAVE_NWG - 1) / WAVE_NWG, p.B), dim3(64 * WAVE_NWG), lds, s, p);
         return;
     }
     static LdsAttr attr;
     auto kern = mbconv_front_wave_kernel<K, S, TW, TH, KCH, 1>;
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), esz);
-    hipLaunchKernelGGL(kern, dim3(tiles, p.B), dim3(64), esz, s, p);
+    CCVPE_LAUNCH(kern, dim3(tiles, p.B), dim3(64), esz, s, p);
 }
 
 template <int K, int S, int TW, int TH>
@@ -362,7 +362,7 @@ static void launch_mb(const MbFrontParams& p, hipStream_t s) {
     auto kern = mbconv_front_kernel<K, S, TW, TH>;
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     const int tiles = ((p.OW + TW - 1) / TW) * ((p.OH + TH - 1) / TH);
-    hipLaunchKernelGGL(kern, dim3(tiles, p.B), dim3(256), lds, s, p);
+    CCVPE_LAUNCH(kern, dim3(tiles, p.B), dim3(256), lds, s, p);
 }
 
 // output tile per (k, stride): stride-1 blocks 8x8, stride-2 blocks 8x4 (k3) / 8x2 (k5) - their input tiles are

@@ -479,7 +479,7 @@ static void launch_img(const MbFrontParams& p, const ImgPlan& pl, hipStream_t s)
     const bool stamp = ++calls % 8 == 0;
     if (stamp) { (void)hipStreamSynchronize(s); unsigned long long z[12] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mi_clk), z, sizeof z); }
 #endif
-    hipLaunchKernelGGL(kern, dim3(std::min(total, NT == 512 ? 256 : 512)), dim3(NT), pl.lds, s, q);   // persistent: 8 waves per CU either way
+    CCVPE_LAUNCH(kern, dim3(std::min(total, NT == 512 ? 256 : 512)), dim3(NT), pl.lds, s, q);   // persistent: 8 waves per CU either way
 #if CCVPE_SE_CLOCK
     if (p.se.counter && p.se.spec && p.mid >= 480) {
         (void)hipStreamSynchronize(s);

@@ -108,9 +108,9 @@ int launch_resize(const ResizeParams& p_in, hipStream_t s) {
     ResizeParams p = p_in;
     if (p.IW > 8 * p.OW || p.IH > 8 * p.OH) return -1;      // more taps than RS_MAXK
     auto blocks = [](long long total) { long long b = (total + 255) / 256; return (int)(b > 256 * 32 ? 256 * 32 : b); };
-    if (p.IW != p.OW) hipLaunchKernelGGL(resize_h_kernel, dim3(blocks((long long)p.B * p.IH * p.OW)), dim3(256), 0, s, p);
+    if (p.IW != p.OW) CCVPE_LAUNCH(resize_h_kernel, dim3(blocks((long long)p.B * p.IH * p.OW)), dim3(256), 0, s, p);
     else p.tmp = const_cast<unsigned char*>(p.in);
-    hipLaunchKernelGGL(resize_v_kernel, dim3(blocks((long long)p.B * p.OH * p.crop_w)), dim3(256), 0, s, p);
+    CCVPE_LAUNCH(resize_v_kernel, dim3(blocks((long long)p.B * p.OH * p.crop_w)), dim3(256), 0, s, p);
     return 0;
 }
 

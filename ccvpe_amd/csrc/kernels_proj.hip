@@ -332,7 +332,7 @@ static void launch_proj_lat2(const ConvParams& p, hipStream_t s) {
     static LdsAttr attr;
     auto kern = conv_proj_lat_kernel<CTB, GATE, LS, SEP>;
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * PL_WAVES), lds, s, p);
+    CCVPE_LAUNCH(kern, grid, dim3(64 * PL_WAVES), lds, s, p);
 }
 template <int CTB>
 static void launch_proj_lat(const ConvParams& p, hipStream_t s) {
@@ -353,7 +353,7 @@ static void launch_proj_cfg(const ConvParams& p, hipStream_t s) {
     auto kern = conv_proj_kernel<RT, CT>;
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     const int wgs = (p.M + 16 * RT - 1) / (16 * RT);
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds, s, p);
+    CCVPE_LAUNCH(kern, dim3(wgs), dim3(256), lds, s, p);
 }
 
 // column tiles of a layer the packed weights were made for

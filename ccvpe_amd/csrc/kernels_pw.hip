@@ -160,7 +160,7 @@ static void launch_pw2(const ConvParams& p, hipStream_t s) {
     const int wgs_needed = (mtiles + 3) / 4;
     const int per_cu = std::max(1, std::min(5, (int)(150 * 1024 / lds)));            // workgroups that fit a CU's LDS
     const int gx = std::max(1, std::min(wgs_needed, (256 * per_cu + nblocks - 1) / nblocks));
-    hipLaunchKernelGGL(kern, dim3(gx, nblocks), dim3(256), lds, s, p);
+    CCVPE_LAUNCH(kern, dim3(gx, nblocks), dim3(256), lds, s, p);
 }
 template <int TN>
 static void launch_pw(const ConvParams& p, hipStream_t s) {

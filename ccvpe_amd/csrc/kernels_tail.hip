@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void tail_conv_kernel(const TailConvParams p) 
 void launch_tail_conv(const TailConvParams& p, hipStream_t s) {
     long long total = (long long)p.B * p.H * p.W;
     int blocks = (int)((total + 255) / 256);
-    if (p.cout == 1) hipLaunchKernelGGL(tail_conv_kernel<1>, dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(tail_conv_kernel<2>, dim3(blocks), dim3(256), 0, s, p);
+    if (p.cout == 1) CCVPE_LAUNCH(tail_conv_kernel<1>, dim3(blocks), dim3(256), 0, s, p);
+    else CCVPE_LAUNCH(tail_conv_kernel<2>, dim3(blocks), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(256) void softmax_final_kernel(const SoftmaxParams 
 }
 
 void launch_softmax(const SoftmaxParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(softmax_partial_kernel, dim3(p.chunks, p.B), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(softmax_final_kernel, dim3(p.chunks, p.B), dim3(256), 0, s, p);
+    CCVPE_LAUNCH(softmax_partial_kernel, dim3(p.chunks, p.B), dim3(256), 0, s, p);
+    CCVPE_LAUNCH(softmax_final_kernel, dim3(p.chunks, p.B), dim3(256), 0, s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(1024) void postprocess_kernel(const float* heat, co
 }
 
 void launch_postprocess(const float* heat, const float* ori, int B, int n, PoseOut* out, hipStream_t s) {
-    hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(1024), 0, s, heat, ori, n, out);
+    CCVPE_LAUNCH(postprocess_kernel, dim3(B), dim3(1024), 0, s, heat, ori, n, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64) void metrics_kernel(const PoseOut* pose, const 
 
 void launch_metrics(const PoseOut* pose, const float* heat, int B, int W, int n, const int* gt_index, const float* gt_cos_sin,
                     const double* meter_per_pixel, const double* heading_deg, MetricsOut* out, hipStream_t s) {
-    hipLaunchKernelGGL(metrics_kernel, dim3((B + 63) / 64), dim3(64), 0, s, pose, heat, B, W, n, gt_index, gt_cos_sin, meter_per_pixel, heading_deg, out);
+    CCVPE_LAUNCH(metrics_kernel, dim3((B + 63) / 64), dim3(64), 0, s, pose, heat, B, W, n, gt_index, gt_cos_sin, meter_per_pixel, heading_deg, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -278,7 +278,7 @@ void launch_preprocess(const PreprocParams& p, hipStream_t s) {
     const long long total = (long long)p.B * 3 * p.H * p.crop_w;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, s, p);
+    CCVPE_LAUNCH(preprocess_kernel, dim3(blocks), dim3(256), 0, s, p);
 }
 
 __device__ __forceinline__ void put4(const Dst& d, long long pix, int c, float4 v) {
@@ -314,7 +314,7 @@ void launch_scatter_channels(const float* src, int C, long long P, Dst d0, Dst d
     const long long total = P * (C >> 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(scatter_channels_kernel, dim3(blocks), dim3(256), 0, s, src, C, P, d0, d1, ndst);
+    CCVPE_LAUNCH(scatter_channels_kernel, dim3(blocks), dim3(256), 0, s, src, C, P, d0, d1, ndst);
 }
 
 // NHWC view -> NCHW copy (debug taps only).
@@ -358,20 +358,20 @@ void launch_multi_copy(const MultiCopy& mc, hipStream_t s) {
     unsigned long long mx = 0;
     for (int i = 0; i < mc.count; ++i) mx = std::max(mx, mc.n[i]);
     const int gx = (int)std::min<unsigned long long>((mx / 4 + 255) / 256, 512);
-    hipLaunchKernelGGL(multi_copy_kernel, dim3(std::max(gx, 1), mc.count), dim3(256), 0, s, mc);
+    CCVPE_LAUNCH(multi_copy_kernel, dim3(std::max(gx, 1), mc.count), dim3(256), 0, s, mc);
 }
 
 void launch_fill_random(float* p, size_t n, uint32_t seed, hipStream_t s) {
     if (n == 0) return;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL(fill_random_kernel, dim3(blocks), dim3(256), 0, s, p, n, seed);
+    CCVPE_LAUNCH(fill_random_kernel, dim3(blocks), dim3(256), 0, s, p, n, seed);
 }
 
 void launch_nhwc_to_nchw(const float* in, int in_ld, int coff, int C, int B, int HW, float* out, hipStream_t s) {
     long long total = (long long)B * C * HW;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, in, in_ld, coff, C, B, HW, out);
+    CCVPE_LAUNCH(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, in, in_ld, coff, C, B, HW, out);
 }
 
 }  // namespace ccvpe

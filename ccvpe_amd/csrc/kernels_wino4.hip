@@ -386,12 +386,12 @@ static void launch_wino4_plain(const ConvParams& p_in, hipStream_t s) {
     if (p.split_fused) {
         auto kern = conv_wino4_kernel<NW, true>;
         ensure_dynamic_lds(attr_f, reinterpret_cast<const void*>(kern), lds);
-        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+        CCVPE_LAUNCH(kern, grid, dim3(NW * 64), lds, s, p);
         return;
     }
     auto kern = conv_wino4_kernel<NW, false>;
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+    CCVPE_LAUNCH(kern, grid, dim3(NW * 64), lds, s, p);
     if (p.splitk > 1) launch_splitk_reduce(p, s);
 }
 

@@ -316,7 +316,7 @@ static void launch_wino4p_plain(const ConvParams& p_in, hipStream_t s) {
     const int nblocks = p.wino_nb ? p.wino_nb : (p.wino_n16 + NW - 1) / NW;
     const int resident = (NW == 4 ? 2 : 1) * 256 / (p.splitk > 1 ? p.splitk : 1);
     dim3 grid(std::min(mblocks * nblocks, std::max(resident, 8)), 1, p.splitk > 1 ? p.splitk : 1);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p, (const float*)p.wino4_v, (unsigned)(w4p_v_floats(p) * sizeof(float)));
+    CCVPE_LAUNCH(kern, grid, dim3(NW * 64), lds, s, p, (const float*)p.wino4_v, (unsigned)(w4p_v_floats(p) * sizeof(float)));
     if (p.splitk > 1) launch_splitk_reduce(p, s);
 }
 
@@ -329,7 +329,7 @@ static void launch_wino4p(const ConvParams& p, hipStream_t s) {
     {   // V = B^T d B, once per layer
         const int ngr = (p.Cin + W4P_GCH - 1) / W4P_GCH;
         const int mblocks = p.B * (p.W >> 4) * (p.H >> 4);
-        hipLaunchKernelGGL(wino4_input_transform_kernel, dim3(mblocks * ngr), dim3(256), 0, s, p, p.wino4_v, ngr);
+        CCVPE_LAUNCH(wino4_input_transform_kernel, dim3(mblocks * ngr), dim3(256), 0, s, p, p.wino4_v, ngr);
     }
     if (p.splitk != 255) { launch_wino4p_plain<NW>(p, s); return; }
     ConvParams a = p;

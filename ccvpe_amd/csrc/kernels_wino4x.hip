@@ -461,7 +461,7 @@ static void launch_wino4x_cfg(const ConvParams& p_in, hipStream_t s) {
     static const int grid_override = getenv("CCVPE_X4_GRID") ? std::atoi(getenv("CCVPE_X4_GRID")) : 0;   // dev: workgroups of the persistent grid
     const int resident = grid_override > 0 ? grid_override : (NW == 4 ? 2 : 1) * 256 / (p.splitk > 1 ? p.splitk : 1);
     dim3 grid(std::min(mblocks, std::max(resident, 8)), 1, p.splitk > 1 ? p.splitk : 1);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, p);
+    CCVPE_LAUNCH(kern, grid, dim3(NW * 64), lds, s, p);
 #if CCVPE_X4_CLOCK
     {   // in-kernel clock = shader cycles / (100 MHz reference ticks) x 100 MHz, median over the workgroups (MI355X_MICROARCH.md, DVFS item 6)
         static int calls = 0;

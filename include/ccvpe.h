@@ -97,6 +97,9 @@ typedef struct ccvpe_metrics {
 
 const char* ccvpe_last_error(void);
 const char* ccvpe_version(void);
+/* Kernel launches this THREAD has issued through the library so far (every entry point; eager launches - a replayed hipGraph issues
+ * none).  The difference around a call = its launches: bench.py's `launches_per_frame`.  No reference counterpart. */
+uint64_t ccvpe_launch_count(void);
 
 int ccvpe_create(const ccvpe_config* cfg, ccvpe_handle* out);
 int ccvpe_destroy(ccvpe_handle h);
