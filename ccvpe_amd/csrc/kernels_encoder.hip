@@ -266,9 +266,6 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const StemDwParams q) {
     // A workgroup owns a contiguous run of tiles (round 4; strided before): its tiles belong to one sample, or to two neighbours, so the
     // squeeze-excite ticket below is drawn once or twice per workgroup instead of once per tile
     const int t_lo = (int)((long long)tiles * blockIdx.x / gridDim.x), t_hi = (int)((long long)tiles * (blockIdx.x + 1) / gridDim.x);
-    int se_done = 0;
-    unsigned long long se_last = 0;                                   // samples (relative to the first of this run) whose last ticket we drew
-    const int se_b0 = t_lo / tps;
     if (t_lo < t_hi) fetch(t_lo);
     for (int tile = t_lo; tile < t_hi; ++tile) {
         const int b = tile / tps;
@@ -370,20 +367,18 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const StemDwParams q) {
         if (lane < 8) *reinterpret_cast<f32x4s*>(red + wave * 32 + lane * 4) = pool;
         __syncthreads();
         if (tid < 32) st_sc1(q.pool_partial + ((size_t)b * tps + tr) * 32 + tid, red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]);
-        // squeeze-excite by ticket (ticket.h): the workgroup that completes a sample's tps tiles computes its gates; the stem tile `st`
-        // is free here (the next tile's stem phase starts behind a barrier), the patch is not (its DMA is in flight)
-        ++se_done;
-        if (q.se.counter != nullptr && (tile + 1 == t_hi || (tile + 1) / tps != b)) {
-            if (ticket_arrive(q.se.counter + b, (unsigned)se_done, (unsigned)q.se.per_sample, reinterpret_cast<unsigned*>(st + SE_SCR_FLAG)))
-                se_last |= 1ull << (b - se_b0);                       // computed behind the loop (ticket.h)
-            se_done = 0;
-        }
     }
-    while (se_last) {
-        const int k = __builtin_ctzll(se_last);
-        se_last &= se_last - 1;
-        se_finish<256>(q.se, se_b0 + k, st);
-        __syncthreads();
+    // squeeze-excite by ticket (ticket.h), behind the loop: one ticket per sample this workgroup's run of tiles touched; the workgroup that
+    // completes a sample's tps tiles computes its gates (the stem tile `st` is free: scratch)
+    if (q.se.counter != nullptr && t_lo < t_hi) {
+        const int b_lo = t_lo / tps, b_hi = (t_hi - 1) / tps;
+        for (int bb = b_lo; bb <= b_hi; ++bb) {
+            const int n = min(t_hi, (bb + 1) * tps) - max(t_lo, bb * tps);
+            if (ticket_arrive(q.se.counter + bb, (unsigned)n, (unsigned)q.se.per_sample, reinterpret_cast<unsigned*>(st + SE_SCR_FLAG))) {
+                se_finish<256>(q.se, bb, st);
+                __syncthreads();
+            }
+        }
     }
 }
 

@@ -172,10 +172,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
     // requests itself again): its expand weights after the barrier that ends the previous expand phase, its taps / bias and every
     // wave's first m-tile at the end of that phase.
     int unit = -1;
-    int se_done = 0;                                       // items finished since the last ticket (all of one sample)
-    unsigned long long se_last = 0;                        // samples (relative to the first one of this share) whose last ticket we drew
-    const int se_b0 = it_lo / max(p.se.per_sample, 1);
-    const bool se_single = (it_hi - 1) / max(p.se.per_sample, 1) == se_b0;   // this share lies inside one sample
     const bool se_on = p.se.counter != nullptr;            // per_sample == NST * nchunks items complete a sample
     const bool rows_on = p.se.sqpart != nullptr;           // squeeze rows per item: for the ticket's combining step, or (no ticket) for the project GEMM's prologue
     const bool sq_lane = rows_on && wave == 0 && lane < p.se.SQ;
@@ -342,27 +338,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void mb
             }
         }
         // (red is rewritten only after the next item's first barrier, which wave 0 reaches after these reads)
-        // ---- squeeze-excite by ticket (ticket.h): this workgroup's items of sample b are done when the next item belongs to another
-        // sample (or there is none); whoever completes the sample's NST x nchunks items computes its gates.  The E image is free here.
-        ++se_done;
-        if (se_on && !se_single && (it + 1 == it_hi || (it + 1) / p.se.per_sample != b)) {
-            if (ticket_arrive(p.se.counter + b, (unsigned)se_done, (unsigned)p.se.per_sample, reinterpret_cast<unsigned*>(Es + SE_SCR_FLAG)))
-                se_last |= 1ull << (b - se_b0);            // the gates of this sample are ours to compute - behind the loop (ticket.h)
-            se_done = 0;
-        }
         CCVPE_MI_STAMP(4);
     }
-    if (se_on && se_single) {   // all items of one sample: one ticket, drawn here (latency plans: with the excite weights already requested)
-        if (p.se.spec) se_arrive_and_finish_parts_spec<NT>(p.se, se_b0, (unsigned)(it_hi - it_lo), Es);
-        else if (ticket_arrive(p.se.counter + se_b0, (unsigned)(it_hi - it_lo), (unsigned)p.se.per_sample, reinterpret_cast<unsigned*>(Es + SE_SCR_FLAG)))
-            se_finish_parts<NT>(p.se, se_b0, Es);
-    }
-    // squeeze-excite of the samples this workgroup completed (a contiguous share of the item list spans a few samples at most)
-    while (se_last) {
-        const int k = __builtin_ctzll(se_last);
-        se_last &= se_last - 1;
-        se_finish_parts<NT>(p.se, se_b0 + k, Es);
-        __syncthreads();
+    // ---- squeeze-excite by ticket (ticket.h), behind the loop: one ticket per sample this workgroup's contiguous share of the item list
+    // touched (how many of the sample's NST x nchunks items were ours follows from the share's bounds); whoever completes a sample computes
+    // its gates.  Inside the loop a ticket cost the front kernels 10-20 % at batch 32 (its store drain also waits for the next item's
+    // prefetched operands, its barriers stop the workgroup twice per sample boundary); here every store has long left.  The whole dynamic
+    // LDS is free (the last item's re-requested operands have landed behind the first ticket's drain).
+    if (se_on) {
+        const int b_lo = it_lo / p.se.per_sample, b_hi = (it_hi - 1) / p.se.per_sample;
+        if (b_lo == b_hi && p.se.spec) {   // latency plans: the excite weights are requested before the ticket is drawn
+            se_arrive_and_finish_parts_spec<NT>(p.se, b_lo, (unsigned)(it_hi - it_lo), Es);
+        } else {
+            for (int bb = b_lo; bb <= b_hi; ++bb) {
+                const int n = min(it_hi, (bb + 1) * p.se.per_sample) - max(it_lo, bb * p.se.per_sample);
+                if (ticket_arrive(p.se.counter + bb, (unsigned)n, (unsigned)p.se.per_sample, reinterpret_cast<unsigned*>(Es + SE_SCR_FLAG))) {
+                    se_finish_parts<NT>(p.se, bb, Es);
+                    __syncthreads();
+                }
+            }
+        }
     }
 #if CCVPE_MI_CLOCK
     if (lane == 0) {
@@ -450,7 +445,9 @@ bool mbconv_image_supported(const MbFrontParams& p) {
     if (!img_plan(p, pl)) return false;
     // measured (batch 32): a stride-2 layer wider than 128 pixels gets strips of only 4 output rows (1.4x halo rows, items too
     // short for their two barriers): ground block 3 (80 x 160) 0.195 ms fused against 0.182 ms as two launches - left unfused
-    if (pl.q.NST > 1 && p.s == 2 && p.W > 128) return false;
+    // (batch <= 4 fuses it all the same: there the three launches of the unfused form - expand GEMM, depthwise, squeeze-excite - are what
+    //  costs, 48 us against 25 us for the aerial encoder's block 3 at batch 1)
+    if (pl.q.NST > 1 && p.s == 2 && p.W > 128 && p.B > 4) return false;
     return true;
 }
 

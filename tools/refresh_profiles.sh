@@ -5,7 +5,7 @@
 #                                        concurrency statistics of the default two-stream schedule
 # rocprofv3 gets the interpreter directly after `--` (no env / bash hop).  Steps are chained: a failed one stops the rest.
 set -e -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p "$out"
