@@ -64,7 +64,12 @@ __device__ __forceinline__ void w4_at(const float m0, const float m1, const floa
 
 // FUSED: a split-K launch that reduces itself (igemm_common.h) - slab stores write-through, a ticket per item, the sums behind the loop.
 // A template parameter, not a run-time flag: the kernel sits at exactly 256 registers and any extra path in its loop spills.
-template <int NW, bool FUSED = false>
+// PANEL (split-K launches with at least eight (channel block, K slice) pairs; one-dimensional grid): the work units are dealt
+// PANEL-major - XCD x owns the weight panels x, x + 8, ... and walks ALL their pixel blocks - instead of one K slice per blockIdx.z with
+// the items of a slice cut into eight runs.  A panel (conv6.0 at batch 32: 448 channels x 128 output channels x 36 positions = 8.3 MB) is
+// then streamed into ONE L2 once; cut into runs, every XCD met three of the fifteen panels per slice and the launch fetched 786 MB for
+// 189 MB of algorithmic traffic (profiles/r03_traffic.json), the weights 4-5 times.
+template <int NW, bool FUSED = false, bool PANEL = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino4_kernel(const ConvParams p) {
     static_assert(NW == 4 || NW == 8, "waves w and w + 4 share the k-step w & 3 of a 16-channel group");
     constexpr int NT = NW * 64;
@@ -87,8 +92,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // persistent work loop (see kernels_wino.hip): XCD x owns a contiguous run of items, channel block slowest
     const int xcd = blockIdx.x & 7;
     const int stride = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
-    const int item_begin = xcd * (total >> 3) + min(xcd, total & 7);
-    const int item_end = item_begin + (total >> 3) + (xcd < (total & 7) ? 1 : 0);
+    const int S = p.splitk > 1 ? p.splitk : 1;
+    // PANEL: unit u of this XCD = (its k-th panel, pixel block): panel x + 8 k = (channel block, K slice)
+    const int npanels = (total / mblocks) * S;
+    const int item_begin = PANEL ? 0 : xcd * (total >> 3) + min(xcd, total & 7);
+    const int xpanels = max((npanels - xcd + 7) >> 3, 1);   // panels of this XCD
+    const int item_end = PANEL ? xpanels * mblocks : item_begin + (total >> 3) + (xcd < (total & 7) ? 1 : 0);
     int item = item_begin + ((int)blockIdx.x >> 3);
     if (item >= item_end) return;
     const int item_first = item;
@@ -98,17 +107,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wino4_w), 0, p.wino4_bytes, 0x00020000);
 
-    int nb, b, by, bx;
-#define CCVPE_W4_DECODE(it_, nb_, b_, by_, bx_)                                                          \
+    int nb, b, by, bx, z = PANEL ? 0 : (int)blockIdx.z, z_n = z;
+#define CCVPE_W4_DECODE(it_, nb_, b_, by_, bx_, z_)                                                      \
     {                                                                                                    \
-        nb_ = (it_) / mblocks;                                                                           \
-        const int mb_ = (it_) - nb_ * mblocks;                                                           \
+        int q_, mb_;                                                                                     \
+        if (PANEL) {   /* panel-minor inside the XCD: its workgroups stream all its panels side by side (all 32 on ONE panel met in the same L2 lines at the same time) */ \
+            mb_ = (it_) / xpanels; q_ = xcd + 8 * ((it_) - mb_ * xpanels);                               \
+            nb_ = q_ / S; z_ = q_ - nb_ * S;                                                             \
+        } else { q_ = (it_) / mblocks; mb_ = (it_) - q_ * mblocks; nb_ = q_; }                           \
         b_ = mb_ / (mbx * mby);                                                                          \
         const int rem_ = mb_ - b_ * (mbx * mby);                                                         \
         by_ = rem_ / mbx;                                                                                \
         bx_ = rem_ - by_ * mbx;                                                                          \
     }
-    CCVPE_W4_DECODE(item, nb, b, by, bx);
+    CCVPE_W4_DECODE(item, nb, b, by, bx, z);
 
     // ---- raw patch staging: float4 j = tid + i*NT -> pixel j / 4 of the 18 x 18 region, channels 4 * (j % 4) of the group
     // (register budget: 144 accumulators + 36 weight registers leave ~70 for everything else at two waves per SIMD, so the
@@ -143,13 +155,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // split-K over channel groups (blockIdx.z)
     const int ngr_all = (p.Cin + W4_GCH - 1) / W4_GCH;
-    int g_begin = 0, g_end = ngr_all;
-    if (p.splitk > 1) {
-        const int per = (ngr_all + p.splitk - 1) / p.splitk;
-        g_begin = min((int)blockIdx.z * per, ngr_all);
-        g_end = min(g_begin + per, ngr_all);
-    }
-    if (g_begin >= g_end) return;   // empty split-K slice (the host never launches one)
+    const int g_per = (ngr_all + S - 1) / S;          // channel groups per K slice (the host never launches an empty slice)
+    int g_begin = min(z * g_per, ngr_all), g_end = min(g_begin + g_per, ngr_all);
+    if (g_begin >= g_end) return;
     // the layer's last group may hold only 8 real channels (Cin % 16 == 8: 40, 56, 104, 200 ...): its k-steps 2 and 3 would
     // multiply zeros, so they are neither transformed nor run (conv2.2: 10 k-steps instead of 12)
     const int tail_ks = (p.Cin - (ngr_all - 1) * W4_GCH + 3) >> 2;
@@ -200,8 +208,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int item_n = item + stride;
         const bool have_n = item_n < item_end;
         int nb_n, b_n, by_n, bx_n;
-        CCVPE_W4_DECODE(have_n ? item_n : item, nb_n, b_n, by_n, bx_n);
+        CCVPE_W4_DECODE(have_n ? item_n : item, nb_n, b_n, by_n, bx_n, z_n);
         const unsigned w_base_n = have_n ? CCVPE_W4_WBASE(nb_n) : OOB;
+        const int g_begin_n = PANEL ? min(z_n * g_per, ngr_all) : g_begin;       // (PANEL: the next unit may belong to another K slice)
 
         for (int g = g_begin; g < g_end; ++g) {
             const bool last_group = g == g_end - 1;
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             __syncthreads();   // V image complete; every wave is done with the raw patch
             // ---- the patch after this one: next group of this tile, or the first group of the next tile ----
-            const int c0n = last_group ? g_begin * W4_GCH : (g + 1) * W4_GCH;
+            const int c0n = last_group ? g_begin_n * W4_GCH : (g + 1) * W4_GCH;
             if (last_group) { CCVPE_W4_ROFF(b_n, by_n, bx_n, have_n); }
             CCVPE_W4_LOAD_RAW(c0n, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int ks = 0; ks < nks; ++ks) {
                 const bool last_step = last_group && ks == nks - 1;
                 const unsigned wb = last_step ? w_base_n : w_base;
-                const int ksn = last_step ? g_begin * 4 : g * 4 + ks + 1;
+                const int ksn = last_step ? g_begin_n * 4 : g * 4 + ks + 1;
                 const float* va = va0 + ks * (18 * 128);
                 f32x2 fa[3];              // V pairs, read two pairs (4 MFMAs = 128 cycles) ahead of their use
                 fa[0] = *reinterpret_cast<const f32x2*>(va);
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const f32x4 bias = (split || !nok) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(p.bias + n);
             const float lo = act == ACT_RELU ? 0.f : -__builtin_inff();   // ReLU as a select: no branch per store
             const size_t pix0 = ((size_t)b * p.H + (size_t)by * 16) * p.W + (size_t)bx * 16;
-            float* obase = split ? p.partial + ((size_t)blockIdx.z * p.M + pix0) * p.N : p.dst[0].ptr + pix0 * ld + p.dst[0].coff;
+            float* obase = split ? p.partial + ((size_t)z * p.M + pix0) * p.N : p.dst[0].ptr + pix0 * ld + p.dst[0].coff;
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0x7fffffff, 0x00020000);
             const int oty = (lane >> 2) & 3, otx = lane & 3;
             const unsigned o_lane = nok ? (unsigned)((((oty * 4) * p.W + otx * 4) * ld + n) * 4) : OOB;
@@ -343,20 +352,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // self-reducing split-K (igemm_common.h): the last K slice of this (pixel block, channel block) sums the slabs and stores the
             // block; the V image is free here (its first word is the ticket's flag), the raw patch of the next item is not touched
             // (the sum itself runs behind the loop: next to the loop's prefetch state its registers spill)
-            if (splitk_ticket(p, item, reinterpret_cast<unsigned*>(Vs))) fin_mask |= 1ull << ordinal;
+            if (splitk_ticket(p, nb * mblocks + (b * mby + by) * mbx + bx, reinterpret_cast<unsigned*>(Vs))) fin_mask |= 1ull << ordinal;
         }
         if (FUSED) ++ordinal;
         if (!have_n) break;
 #pragma unroll
         for (int x = 0; x < 36; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
         item = item_n; nb = nb_n; b = b_n; by = by_n; bx = bx_n; w_base = w_base_n;
+        if (PANEL) { z = z_n; g_begin = g_begin_n; g_end = min(g_begin + g_per, ngr_all); }
     }
     // the regions whose last ticket this workgroup drew (the launcher keeps a workgroup's items <= 64 when the launch reduces itself)
     while (FUSED && fin_mask) {
         const int k = __builtin_ctzll(fin_mask);
         fin_mask &= fin_mask - 1;
-        int nb_f, b_f, by_f, bx_f;
-        CCVPE_W4_DECODE(item_first + k * stride, nb_f, b_f, by_f, bx_f);
+        int nb_f, b_f, by_f, bx_f, z_f = 0;
+        CCVPE_W4_DECODE(item_first + k * stride, nb_f, b_f, by_f, bx_f, z_f);
+        (void)z_f;
         splitk_finish<NT>(p, (b_f * p.H + by_f * 16) * p.W + bx_f * 16, 16, 16, p.W, nb_f * NW * 16, NW * 16);
     }
 #undef CCVPE_W4_DECODE
@@ -377,22 +388,27 @@ static void launch_wino4_plain(const ConvParams& p_in, hipStream_t s) {
     }
     constexpr size_t lds = (W4_VFLOATS + W4_GCH * W4_PLANE) * sizeof(float);
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    static LdsAttr attr, attr_f;
+    static LdsAttr attr, attr_f, attr_p, attr_pf;
     const int mblocks = p.B * (p.W >> 4) * (p.H >> 4);
     const int nblocks = p.wino_nb ? p.wino_nb : (p.wino_n16 + NW - 1) / NW;
-    const int resident = (NW == 4 ? 2 : 1) * 256 / (p.splitk > 1 ? p.splitk : 1);   // 256-thread workgroups: two per CU, 512-thread: one
-    dim3 grid(std::min(mblocks * nblocks, std::max(resident, 8)), 1, p.splitk > 1 ? p.splitk : 1);
-    if (p.splitk <= 1 || p.tickets == nullptr || mblocks * nblocks > CONV_TICKETS || (mblocks * nblocks + (int)grid.x - 1) / (int)grid.x + 1 > 64) p.split_fused = 0;
-    if (p.split_fused) {
-        auto kern = conv_wino4_kernel<NW, true>;
-        ensure_dynamic_lds(attr_f, reinterpret_cast<const void*>(kern), lds);
-        CCVPE_LAUNCH(kern, grid, dim3(NW * 64), lds, s, p);
-        return;
-    }
-    auto kern = conv_wino4_kernel<NW, false>;
+    const int S = p.splitk > 1 ? p.splitk : 1;
+    // Opt-in (CCVPE_WINO4_PANEL=1), measured in round 4 on conv6.0 at batch 32 (profiles/r04_traffic.json): fabric-side traffic 786 MB ->
+    // 529 MB per launch (414 MB with the XCD's workgroups all on one panel at a time, but that form runs 4 % slower: 32 CUs meet in the
+    // same L2 lines), the launch alone 1.7 % faster, the whole two-stream step 0.3 % slower - so the default stays one K slice per blockIdx.z.
+    static const bool want_panel = getenv("CCVPE_WINO4_PANEL") && std::atoi(getenv("CCVPE_WINO4_PANEL")) == 1;
+    const bool panel = S > 1 && nblocks * S >= 8 && want_panel;   // panel-major units, one-dimensional grid (see the kernel's comment)
+    const int resident = (NW == 4 ? 2 : 1) * 256 / (panel ? 1 : S);   // 256-thread workgroups: two per CU, 512-thread: one
+    dim3 grid(std::min(mblocks * nblocks * (panel ? S : 1), std::max(resident, 8)), 1, panel ? 1 : S);
+    const int per_wg = (mblocks * nblocks * (panel ? S : 1) + (int)grid.x - 1) / (int)grid.x + 8;   // (upper bound of a workgroup's units)
+    if (S <= 1 || p.tickets == nullptr || mblocks * nblocks > CONV_TICKETS || per_wg > 64) p.split_fused = 0;
+    const dim3 block(NW * 64);
+    if (panel && p.split_fused) { auto kern = conv_wino4_kernel<NW, true, true>; ensure_dynamic_lds(attr_pf, reinterpret_cast<const void*>(kern), lds); CCVPE_LAUNCH(kern, grid, block, lds, s, p); return; }
+    if (panel) { auto kern = conv_wino4_kernel<NW, false, true>; ensure_dynamic_lds(attr_p, reinterpret_cast<const void*>(kern), lds); CCVPE_LAUNCH(kern, grid, block, lds, s, p); launch_splitk_reduce(p, s); return; }
+    if (p.split_fused) { auto kern = conv_wino4_kernel<NW, true, false>; ensure_dynamic_lds(attr_f, reinterpret_cast<const void*>(kern), lds); CCVPE_LAUNCH(kern, grid, block, lds, s, p); return; }
+    auto kern = conv_wino4_kernel<NW, false, false>;
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
-    CCVPE_LAUNCH(kern, grid, dim3(NW * 64), lds, s, p);
-    if (p.splitk > 1) launch_splitk_reduce(p, s);
+    CCVPE_LAUNCH(kern, grid, block, lds, s, p);
+    if (S > 1) launch_splitk_reduce(p, s);
 }
 
 // cfg split code 255 = "tail split": when the work items are a whole number of rounds of the resident workgroups plus a
