@@ -110,7 +110,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         }
         if (ticket) {
             tick_off = pl.alloc_tickets((size_t)B);
-            se.per_sample = with_stem ? S : image ? S * (mid / 16) : S;   // tiles | (strip, 16-channel chunk) items | workgroups of a sample
+            se.per_sample = with_stem ? S : image ? S * (mid / 16) : S * mbconv_front_ticket_split(mp);   // tiles | (strip, 16-channel chunk) items | workgroups of a sample
             se.S = S; se.C = mid; se.SQ = bw.sq; se.inv_hw = 1.f / (float)(oh * ow);
             se.w1 = bw.se_w1; se.b1 = bw.se_b1; se.w2 = bw.se_w2; se.b2 = bw.se_b2;
             se.spec = (long long)B * se.per_sample <= 256 ? 1 : 0;   // latency plans: one workgroup per item, the chip not even filled once

@@ -244,6 +244,7 @@ int mbconv_front_tiles(int k, int s, int OH, int OW);
 // 0 = the kernel launch_mbconv_front / launch_mbconv_image would pick for these parameters does not take a ticket
 int mbconv_front_ticket_rows(const MbFrontParams& p);
 int mbconv_image_ticket_rows(const MbFrontParams& p);
+int mbconv_front_ticket_split(const MbFrontParams& p);   // workgroups per tile group of the wave form (channel ranges): tickets per row
 bool mbconv_front_supported(int k, int s, int cin, int mid);
 bool mbconv_front_profitable(int k);
 // image-resident form (kernels_mbimg.hip): the whole image, or horizontal strips of it, per 16-channel chunk in LDS

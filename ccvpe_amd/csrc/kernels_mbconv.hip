@@ -203,8 +203,13 @@ __global__ __launch_bounds__(64 * NWG, KCH == 1 ? 3 : 2) void mbconv_front_wave_
     const int tiles = tiles_x * ((p.OH + TH - 1) / TH);
     const int tile = blockIdx.x * NWG + wave, b = blockIdx.y;
     const bool live = tile < tiles;          // (ragged last workgroup: a wave without a tile contributes zeros)
+    // latency plans (NWG > 1, gridDim.z > 1): the 16-channel chunks of a tile are dealt to gridDim.z workgroups - a wave then walks
+    // 2 chunks instead of 6 (block 1 at batch 1: every chunk is a chain of weight, tap and LDS latencies nothing else on the CU hides)
+    const int nch = p.mid >> 4;
+    const int c_lo = NWG > 1 ? 16 * (int)(((long long)nch * blockIdx.z) / gridDim.z) : 0;
+    const int c_hi = NWG > 1 ? 16 * (int)(((long long)nch * (blockIdx.z + 1)) / gridDim.z) : p.mid;
     if (NWG > 1 && !live)
-        for (int c = lane; c < p.mid; c += 64) psum[wave * p.mid + c] = 0.f;
+        for (int c = c_lo + lane; c < c_hi; c += 64) psum[wave * p.mid + c] = 0.f;
     if (live) {
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(64 * NWG, KCH == 1 ? 3 : 2) void mbconv_front_wave_
         vmask |= (ok ? 1u : 0u) << mt;
     }
     const int q = lane & 3, slot = lane >> 2;    // depthwise: channel quad q of the chunk, output slot (16 slots x OPL outputs)
-    for (int ch0 = 0; ch0 < p.mid; ch0 += 16) {
+    for (int ch0 = c_lo; ch0 < c_hi; ch0 += 16) {
         // ---- expand: E[px][n] = swish(sum_c X[px][c] We[ch0 + n][c] + be) for the NIP input pixels ----
         f32x4 wfrag[KCH];                        // B fragments: We[ch0 + (lane & 15)][16 kc + 4 (lane >> 4) + e]
 #pragma unroll
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(64 * NWG, KCH == 1 ? 3 : 2) void mbconv_front_wave_
     if constexpr (NWG > 1) {
         // one partial row per workgroup (waves in wave order: deterministic), then the squeeze-excite ticket; the E tiles are free
         __syncthreads();
-        for (int c = threadIdx.x; c < p.mid; c += 64 * NWG) {
+        for (int c = c_lo + threadIdx.x; c < c_hi; c += 64 * NWG) {   // (the workgroups of a tile group write disjoint channels of one row)
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < NWG; ++w) s += psum[w * p.mid + c];
@@ -333,6 +338,7 @@ __global__ __launch_bounds__(64 * NWG, KCH == 1 ? 3 : 2) void mbconv_front_wave_
 }
 
 static constexpr int WAVE_NWG = 4;   // waves per workgroup of the ticket form
+int mbconv_front_ticket_split(const MbFrontParams& p);
 
 template <int K, int S, int TW, int TH, int KCH>
 static void launch_mb_wave(const MbFrontParams& p, hipStream_t s) {
@@ -344,7 +350,7 @@ static void launch_mb_wave(const MbFrontParams& p, hipStream_t s) {
         static LdsAttr attr4;
         auto kern = mbconv_front_wave_kernel<K, S, TW, TH, KCH, WAVE_NWG>;
         ensure_dynamic_lds(attr4, reinterpret_cast<const void*>(kern), lds);
-        CCVPE_LAUNCH(kern, dim3((tiles + WAVE_NWG - 1) / WAVE_NWG, p.B), dim3(64 * WAVE_NWG), lds, s, p);
+        CCVPE_LAUNCH(kern, dim3((tiles + WAVE_NWG - 1) / WAVE_NWG, p.B, mbconv_front_ticket_split(p)), dim3(64 * WAVE_NWG), lds, s, p);
         return;
     }
     static LdsAttr attr;
@@ -394,6 +400,15 @@ static bool wave_form_serves(const MbFrontParams& p) {
 int mbconv_front_ticket_rows(const MbFrontParams& p) {
     if (!wave_form_serves(p) || p.mid > 1152) return 0;
     return (mbconv_front_tiles(p.k, p.s, p.OH, p.OW) + WAVE_NWG - 1) / WAVE_NWG;
+}
+
+// ... and how many workgroups share a tile group's channels (each draws a ticket: SeTicket::per_sample = rows x this).  More than one only
+// in latency plans: the launch then has ~384 workgroups of four waves, three per CU beside the other encoder's
+int mbconv_front_ticket_split(const MbFrontParams& p) {
+    static const bool off = getenv("CCVPE_FRONT_SPLIT") != nullptr && std::atoi(getenv("CCVPE_FRONT_SPLIT")) == 0;
+    const int rows = mbconv_front_ticket_rows(p);
+    if (rows == 0 || off || (long long)rows * p.B > 192) return 1;
+    return std::max(1, std::min(p.mid / 16, 384 / (rows * p.B)));
 }
 
 void launch_mbconv_front(const MbFrontParams& p, hipStream_t s) {

@@ -410,6 +410,7 @@ struct ImgPlan {
 // Whole image if it fits the LDS of a CU, else the fewest equal strips that do (their halo rows are expanded twice).  Per strip count:
 // whole-tile staging, else half tiles; two 256-thread workgroups per CU where both fit (out of phase: one's depthwise phase beside the
 // other's expand phase), else one of 512.
+static void img_plan_spread(const MbFrontParams& p, ImgPlan& pl);
 static bool img_plan(const MbFrontParams& p, ImgPlan& pl) {
     const size_t cap = 158 * 1024;
     const int kch = p.cinp / 16;
@@ -428,9 +429,40 @@ static bool img_plan(const MbFrontParams& p, ImgPlan& pl) {
         else if (kch > 2 && img_geometry_ro(p, pl.tx, pl.ty, ro, 8, hk, pl.q) <= cap) { pl.nt = 512; pl.sk = hk; }
         else { if (ro <= pl.ty) break; continue; }
         pl.lds = img_geometry_ro(p, pl.tx, pl.ty, ro, pl.nt / 64, pl.sk, pl.q);
-        return (ro - 1) * p.s + p.k <= 4 * ro * p.s;   // not worth it once the halo is 4x the strip
+        if ((ro - 1) * p.s + p.k > 4 * ro * p.s) return false;   // not worth it once the halo is 4x the strip
+        img_plan_spread(p, pl);
+        return true;
     }
     return false;
+}
+
+// Latency plans (round 4).  With one sample a block is 15-72 chunks - as many workgroups on 256 CUs - and the expand GEMM of a chunk runs
+// on ONE CU's matrix pipe: 256 pixels x 192 channels x 16 = 6100 cycles of fp32 MFMAs, 1024 x 112 x 16 = 14300 (in-kernel stamps, batch 1:
+// the expand phase is 50-65 % of a workgroup's 7-15 us and under 1 % of it waits for memory).  More, shorter strips put the same chunk on
+// several CUs: the halo rows are expanded twice, the chip has the room.  Taken when the items still fit the chip in one round and a strip
+// reads at least a fifth fewer rows than the plan above.
+static void img_plan_spread(const MbFrontParams& p, ImgPlan& pl) {
+    static const int cap_items = getenv("CCVPE_IMG_SPREAD") != nullptr ? std::atoi(getenv("CCVPE_IMG_SPREAD")) : 128;   // items a launch may spread to - half the chip: the other stream runs the other encoder's front beside it (256: 1.25, 192: 1.22, 128: 1.20 ms per frame, 0 = off: 1.27)
+    const int chunks = p.mid / 16, kch = p.cinp / 16;
+    if ((long long)p.B * pl.q.NST * chunks > cap_items / 2) return;
+    const size_t cap = 158 * 1024;
+    int best_rows = std::min(p.H, (pl.q.RO - 1) * p.s + p.k);
+    for (int nst = pl.q.NST + 1; nst <= p.OH; ++nst) {
+        const int ro0 = (p.OH + nst - 1) / nst;
+        int tx, ty;
+        patch_sel(ro0, p.OW, p.s, tx, ty);
+        const int ro = (ro0 + ty - 1) / ty * ty;
+        const int n = (p.OH + ro - 1) / ro;
+        if ((long long)p.B * n * chunks > cap_items) break;
+        const int rows = std::min(p.H, (ro - 1) * p.s + p.k);
+        if (rows * 5 > best_rows * 4 || rows > 4 * ro * p.s) continue;
+        ImgPlan c = pl;
+        c.tx = tx; c.ty = ty; c.nt = 512; c.sk = kch;
+        if (img_geometry_ro(p, tx, ty, ro, 8, kch, c.q) > cap) continue;
+        c.lds = img_geometry_ro(p, tx, ty, ro, 8, kch, c.q);
+        pl = c;
+        best_rows = rows;
+    }
 }
 
 // Cin need not be a multiple of 16: the expand weights are zero padded to cinp and the last 16-byte pieces of a pixel then

@@ -148,9 +148,13 @@ static constexpr int PL_WAVES = 16;
 // a wave holds channels 16 s + 4 kq .. + 3 of its steps' activations and takes the excite rows j = r, r + 16, ...: three 16-byte loads
 // per step for SQ = 48, a butterfly over the 16 lanes of a quad, a sigmoid - the gate quad lands in the lane that multiplies it into
 // its A fragment.  Every request (activations, weights, excite rows, squeeze rows) goes out before the first wait.
-template <int CTB, bool GATE, int LS, bool SEP>
+// RTB > 1 (no gate): RTB row tiles per workgroup - a weight fragment serves RTB MFMAs and the layer's weights are read M / (16 RTB) times
+// instead of M / 16 times.  The level-6 transposed convs and the aerial descriptor conv at batch 1 (64 rows, 21-26 MB of weights) ran at
+// 1 TB/s with four row-tile workgroups per column tile on four different XCDs, each pulling the panel through its own L2.
+template <int CTB, bool GATE, int LS, bool SEP, int RTB = 1>
 __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const ConvParams p) {
     static_assert(!SEP || GATE, "SEP computes what GATE multiplies");
+    static_assert(RTB == 1 || !GATE, "one gate vector per row tile: the multi-row form is for the layers without a gate");
     constexpr unsigned OOB = 0x80000000u;
     constexpr int SEJ = 3;                                         // excite rows per lane and step: SQ <= 16 * SEJ = 48 (EfficientNet-B0: <= 48)
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [16 waves][CTB][64 lanes][4]; SEP: group partials and sq[] first
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
     const int nsteps = spt * taps;
     const int per = (nsteps + PL_WAVES - 1) / PL_WAVES;
     const int s_begin = min(wave * per, nsteps), s_end = min(s_begin + per, nsteps);
-    const int m0 = blockIdx.x * 16;
+    const int m0 = blockIdx.x * 16 * RTB;
     const int ct_all = (p.N + 15) >> 4, t0 = blockIdx.y * CTB;
 
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
@@ -171,27 +175,28 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
                                               : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE ? p.gate : p.in), 0, GATE ? p.gate_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.proj_w), 0, p.proj_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t b2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SEP ? p.se_b2 : p.in), 0, SEP ? (unsigned)(p.Cin * 4) : 0u, 0x00020000);
-    const int m = m0 + (lane & 15);
+    const int m = m0 + (lane & 15);                                // (row of tile 0; tile r: + 16 r)
     const bool ok = m < p.M;
-    // base address of this lane's row per tap (1x1: the row itself; k2s2: the four pixels of its 2 x 2 patch)
-    unsigned a_tap[4];
-    {
-        const int mm = ok ? m : 0;
+    // base address of this lane's row in every row tile (1x1: the row itself; k2s2: the first pixel of its 2 x 2 patch - the other taps
+    // are a uniform distance away and ride in the scalar offset)
+    unsigned a_row[RTB];
+#pragma unroll
+    for (int r = 0; r < RTB; ++r) {
+        const int mr = m + 16 * r;
+        if (SEP) { a_row[r] = mr < p.M ? (unsigned)mr * (unsigned)p.in_ld * 4u + (unsigned)kq4 * 4u : OOB; continue; }   // (SEP: 1x1 only - the row itself)
+        const int mm = mr < p.M ? mr : 0;
         const int b = mm / ohw, rem = mm - b * ohw;
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
-#pragma unroll
-        for (int t = 0; t < (SEP ? 1 : 4); ++t) {
-            const int ky = t / p.KW, kx = t - ky * p.KW;
-            const int iy = oy * p.stride + ky, ix = ox * p.stride + kx;
-            a_tap[t] = (ok && t < taps) ? (unsigned)((b * p.H + iy) * p.W + ix) * (unsigned)p.in_ld * 4u + (unsigned)kq4 * 4u : OOB;
-        }
+        a_row[r] = mr < p.M ? (unsigned)((b * p.H + oy * p.stride) * p.W + ox * p.stride) * (unsigned)p.in_ld * 4u + (unsigned)kq4 * 4u : OOB;
     }
     const unsigned g_off = ok ? (unsigned)(m / ohw) * (unsigned)p.Cin * 4u + (unsigned)kq4 * 4u : OOB;
     const unsigned w_lane = (unsigned)lane * 16u;
 
-    f32x4 acc[CTB];
+    f32x4 acc[CTB][RTB];
 #pragma unroll
-    for (int t = 0; t < CTB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < CTB; ++t)
+#pragma unroll
+        for (int r = 0; r < RTB; ++r) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
     // SEP: this thread's share of the squeeze rows (requested first; summed behind the operand requests of the first group)
     const int se_g = SEP ? tid / max(p.se_sq, 1) : 0, se_j = SEP ? tid - se_g * p.se_sq : 0;
     const int se_G = SEP ? min(64 * PL_WAVES / max(p.se_sq, 1), 16) : 1;      // groups: rows g, g + G, ...
@@ -224,16 +229,19 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
     do {   // (at least one pass per wave, also for a wave without steps - all its requests out of range: the SEP barriers below are for everybody)
         // every operand of the group, requested at once (steps past s_end and column tiles past the layer's ask for out-of-range
         // offsets: zeros, no traffic)
-        f32x4 a[LS], g[LS], w[LS][CTB];
+        f32x4 a[LS][RTB], g[LS], w[LS][CTB];
         f32x4 ew[SEP ? LS : 1][SEP ? SEJ : 1];
 #pragma unroll
         for (int i = 0; i < LS; ++i) {
             const int s = sg + i;
             const bool live = s < s_end;
-            const int tap = taps == 1 ? 0 : s / spt;                 // (scalar: s is wave-uniform)
+            const int tap = (SEP || taps == 1) ? 0 : s / spt;        // (scalar: s is wave-uniform; SEP: one tap)
             const int sub = s - tap * spt;
-            const unsigned ab = tap == 0 ? a_tap[0] : tap == 1 ? a_tap[1] : tap == 2 ? a_tap[2] : a_tap[3];
-            if (!SEP) a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, live ? ab : OOB, sub * 64, 0));
+            const int tap_off = (SEP || taps == 1) ? 0 : ((tap / p.KW) * p.W + tap % p.KW) * p.in_ld * 4;   // (scalar)
+            if (!SEP) {
+#pragma unroll
+                for (int r = 0; r < RTB; ++r) a[i][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, live ? a_row[r] : OOB, tap_off + sub * 64, 0));
+            }
             if (SEP) {
 #pragma unroll
                 for (int e = 0; e < SEJ - 1; ++e) {   // excite row j = (lane & 15) + 16 e at channels 16 s + 4 kq .. + 3 (rows 32 .. 47: below)
@@ -287,50 +295,58 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
 #pragma unroll
                 for (int t = 0; t < CTB; ++t) w[i][t] *= gq;
                 __builtin_amdgcn_sched_barrier(0);
-                a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, s < s_end ? a_tap[0] : OOB, s * 64, 0));   // (SEP: one tap)
+                a[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, s < s_end ? a_row[0] : OOB, s * 64, 0));   // (SEP: one tap)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
         for (int i = 0; i < LS; ++i) {
-            if (GATE && !SEP) a[i] *= g[i];
+            if (GATE && !SEP) a[i][0] *= g[i];
 #pragma unroll
-            for (int t = 0; t < CTB; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].x, a[i].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].y, a[i].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].z, a[i].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].w, a[i].w, acc[t], 0, 0, 0);
-            }
+            for (int t = 0; t < CTB; ++t)
+#pragma unroll
+                for (int r = 0; r < RTB; ++r) {
+                    acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].x, a[i][r].x, acc[t][r], 0, 0, 0);
+                    acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].y, a[i][r].y, acc[t][r], 0, 0, 0);
+                    acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].z, a[i][r].z, acc[t][r], 0, 0, 0);
+                    acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][t].w, a[i][r].w, acc[t][r], 0, 0, 0);
+                }
         }
         __builtin_amdgcn_sched_barrier(0);
         sg += LS;
     } while (sg < s_end);
 #undef CCVPE_PL_LATE_REQUESTS
-    // ---- the sixteen K-partials meet in LDS; wave t < CTB adds column tile t in wave order and stores it ----
+    // ---- the sixteen K-partials meet in LDS; wave t < CTB x RTB adds (column tile, row tile) t in wave order and stores it ----
+    constexpr int NTL = CTB * RTB;
+    static_assert(NTL <= PL_WAVES, "one wave per tile of the workgroup in the epilogue");
 #pragma unroll
-    for (int t = 0; t < CTB; ++t) *reinterpret_cast<f32x4*>(smem + ((wave * CTB + t) * 64 + lane) * 4) = acc[t];
+    for (int t = 0; t < CTB; ++t)
+#pragma unroll
+        for (int r = 0; r < RTB; ++r) *reinterpret_cast<f32x4*>(smem + ((wave * NTL + t * RTB + r) * 64 + lane) * 4) = acc[t][r];
     __syncthreads();
-    if (wave < CTB && t0 + wave < ct_all) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(smem + ((0 * CTB + wave) * 64 + lane) * 4);
+    const int ct_w = wave / RTB, rt_w = wave - ct_w * RTB;           // (scalar)
+    if (wave < NTL && t0 + ct_w < ct_all) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(smem + ((0 * NTL + wave) * 64 + lane) * 4);
 #pragma unroll
-        for (int w2 = 1; w2 < PL_WAVES; ++w2) v += *reinterpret_cast<const f32x4*>(smem + ((w2 * CTB + wave) * 64 + lane) * 4);
-        const int n = (t0 + wave) * 16 + kq4;
-        if (ok && n < p.N) {
+        for (int w2 = 1; w2 < PL_WAVES; ++w2) v += *reinterpret_cast<const f32x4*>(smem + ((w2 * NTL + wave) * 64 + lane) * 4);
+        const int n = (t0 + ct_w) * 16 + kq4;
+        const int mo = m + 16 * rt_w;
+        if (mo < p.M && n < p.N) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i] + (n + i < p.N ? p.bias[n + i] : 0.f), p.act);
-            emit_out4(p, m, n, v);
+            emit_out4(p, mo, n, v);
         }
     }
 }
 
 static int proj_lat_steps(const ConvParams& p) { return ((p.Cin + 15) / 16) * p.KH * p.KW; }
 
-template <int CTB, bool GATE, int LS, bool SEP = false>
+template <int CTB, bool GATE, int LS, bool SEP = false, int RTB = 1>
 static void launch_proj_lat2(const ConvParams& p, hipStream_t s) {
-    constexpr size_t lds = ((size_t)PL_WAVES * CTB * 64 * 4 + (SEP ? 16 * 64 + 64 : 0)) * sizeof(float);
-    const dim3 grid((p.M + 15) / 16, ((p.N + 15) / 16 + CTB - 1) / CTB);
+    constexpr size_t lds = ((size_t)PL_WAVES * CTB * RTB * 64 * 4 + (SEP ? 16 * 64 + 64 : 0)) * sizeof(float);
+    const dim3 grid((p.M + 16 * RTB - 1) / (16 * RTB), ((p.N + 15) / 16 + CTB - 1) / CTB);
     static LdsAttr attr;
-    auto kern = conv_proj_lat_kernel<CTB, GATE, LS, SEP>;
+    auto kern = conv_proj_lat_kernel<CTB, GATE, LS, SEP, RTB>;
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);
     CCVPE_LAUNCH(kern, grid, dim3(64 * PL_WAVES), lds, s, p);
 }
@@ -369,6 +385,7 @@ bool conv_proj_supported(const ConvParams& p, int rt) {
               p.in_ld % 4 == 0 && p.Cin >= 64 && p.M <= 4096)) return false;
         if ((p.gate != nullptr || p.se_rows != nullptr) && p.Cin % 16 != 0) return false;      // (the gate vector has exactly Cin entries per sample)
         if (rt == 104 && p.gate != nullptr) return false;              // (gates + four column tiles of weights per step: past the 128 registers of a wave)
+        if (rt > 104 && (p.gate != nullptr || p.se_rows != nullptr || p.M < 16 * ((rt - 100) / 10) || p.M > 1024)) return false;   // the multi-row forms: no gate, at least one full workgroup of rows
         if (p.se_rows != nullptr) {   // gates computed in the prologue: one group per wave, every wave busy, a row tile inside one sample, <= 64 squeeze outputs
             const int steps = proj_lat_steps(p);
             if (rt != 101 || !one || steps > PL_WAVES * 5 || p.se_sq > 48 || p.se_sq < 1 || p.se_nrows > 6 * std::min(1024 / p.se_sq, 16) ||
@@ -395,6 +412,8 @@ void launch_proj(const ConvParams& p, int rt, hipStream_t s) {
     if (rt == 101) { launch_proj_lat<1>(p, s); return; }
     if (rt == 102) { launch_proj_lat<2>(p, s); return; }
     if (rt == 104) { launch_proj_lat<4>(p, s); return; }
+    if (rt == 121) { launch_proj_lat2<1, false, 8, false, 2>(p, s); return; }   // two / four row tiles per workgroup (no gate)
+    if (rt == 141) { launch_proj_lat2<1, false, 4, false, 4>(p, s); return; }
     const int ct = proj_ct(p);
     if (rt == 2 && ct == 5) launch_proj_cfg<2, 5>(p, s);
     else if (rt == 4 && ct == 5) launch_proj_cfg<4, 5>(p, s);

@@ -187,6 +187,9 @@ static const PwTile PW_TILES[] = {
     {16, 16, "conv_projl_1", launch_proj_rt<101>, 101},
     {16, 32, "conv_projl_2", launch_proj_rt<102>, 102},
     {16, 64, "conv_projl_4", launch_proj_rt<104>, 104},
+    // ... with two / four row tiles and one column tile per workgroup: the weights of a 64-row layer are read once (layers without a gate)
+    {32, 16, "conv_projl_r2", launch_proj_rt<121>, 121},
+    {64, 16, "conv_projl_r4", launch_proj_rt<141>, 141},
 };
 int conv_pw_tile_proj_rt(int i) { return i >= 0 && i < (int)(sizeof(PW_TILES) / sizeof(PW_TILES[0])) ? PW_TILES[i].proj_rt : 0; }
 int pw_num_tiles() { return (int)(sizeof(PW_TILES) / sizeof(PW_TILES[0])); }

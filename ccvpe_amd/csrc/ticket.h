@@ -160,7 +160,7 @@ __device__ __forceinline__ void se_finish_jb(const SeTicket& t, int b, float* sc
     if (t.C * 2 <= NT) {
         const int G = NT / t.C;
         const int g = tid / t.C, c = tid - g * t.C;
-        if (g < G) part[g * t.C + c] = se_column_sum<8>(pp, t.C, c, g, G, t.S);
+        if (g < G) part[g * t.C + c] = se_column_sum<32>(pp, t.C, c, g, G, t.S);   // (block 1 at batch 1: 128 rows over two groups - two trips, not eight)
         __syncthreads();
         if (tid < t.C) {
             float v = 0.f;
@@ -168,7 +168,7 @@ __device__ __forceinline__ void se_finish_jb(const SeTicket& t, int b, float* sc
             pooled[tid] = v * t.inv_hw;
         }
     } else {
-        for (int c = tid; c < t.C; c += NT) pooled[c] = se_column_sum<8>(pp, t.C, c, 0, 1, t.S) * t.inv_hw;
+        for (int c = tid; c < t.C; c += NT) pooled[c] = se_column_sum<16>(pp, t.C, c, 0, 1, t.S) * t.inv_hw;
     }
     __syncthreads();
     // (2) squeeze: one (output j, channel quad) product per thread and round into LDS, then thread j adds its C / 4 products in
@@ -222,7 +222,7 @@ __device__ __forceinline__ void se_finish_parts_jb(const SeTicket& t, int b, flo
     const float* rows = t.sqpart + (size_t)b * t.per_sample * t.SQ;
     const int G = min(NT / t.SQ, 1024 / t.SQ);
     const int g = tid / t.SQ, j = tid - g * t.SQ;
-    if (g < G) part[g * t.SQ + j] = se_column_sum<8>(rows, t.SQ, j, g, G, t.per_sample);
+    if (g < G) part[g * t.SQ + j] = se_column_sum<24>(rows, t.SQ, j, g, G, t.per_sample);   // (latency plans with strips: ~200 rows over ten groups - one trip)
     __syncthreads();
     if (tid < t.SQ) {
         float v = 0.f;
