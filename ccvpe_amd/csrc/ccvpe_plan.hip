@@ -72,6 +72,7 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         mp.B = B; mp.H = ch; mp.W = cw; mp.Cin = b.cin; mp.cinp = bw.exp_cinp; mp.mid = mid;
         mp.we = bw.exp_lin; mp.be = bw.expand.bias; mp.wd = bw.dw_w; mp.bd = bw.dw_b;
         mp.k = b.k; mp.s = b.s; mp.pad_t = lo; mp.pad_l = lo; mp.circular = circular; mp.OH = oh; mp.OW = ow;
+        mp.spread = getenv("CCVPE_FRONT_SPREAD") ? std::atoi(getenv("CCVPE_FRONT_SPREAD")) : 128;   // (read per plan: tests toggle it)
         // small-spatial blocks: the whole expanded image of 16 channels lives in LDS (kernels_mbimg.hip); CCVPE_FUSE_MBCONV=0 / CCVPE_MBCONV_IMAGE=0 turn it off
         const bool image_off = getenv("CCVPE_MBCONV_IMAGE") && std::atoi(getenv("CCVPE_MBCONV_IMAGE")) == 0;   // read per plan: tests toggle it
         const bool image = b.e != 1 && bw.exp_lin != nullptr && h->fuse_mbconv != 0 && !image_off && mbconv_image_supported(mp);
@@ -484,6 +485,7 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
         }
         mp.rpad = rpad;
         mp.P = match_pixels_per_block(hw, C);
+        mp.no_wide = (getenv("CCVPE_MATCH_WIDE") && std::atoi(getenv("CCVPE_MATCH_WIDE")) == 0) ? 1 : 0;   // (read per plan: tests toggle it)
         mp.cat_max_ld = 8 + C;
         mp.cat_all_ld = rpad + C;
         Tensor xin = x, lin = loc_in[k];

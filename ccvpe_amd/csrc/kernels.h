@@ -237,6 +237,8 @@ struct MbFrontParams {
     float* pool;               // [B][tiles][mid]
     SeTicket se;               // se.counter != null: squeeze-excite by the last-arriving workgroup of a sample (ticket.h); the kernels
                                // that take it are named by the *_ticket_rows functions below (0 = this launch cannot)
+    int spread;                // latency plans: work items a launch may spread to by cutting its work finer (more strips of the image-resident
+                               // form, channel ranges per tile group of the wave form); 0 = never.  Set by the plan (CCVPE_FRONT_SPREAD, default 128)
 };
 void launch_mbconv_front(const MbFrontParams& p, hipStream_t s);
 int mbconv_front_tiles(int k, int s, int OH, int OW);
@@ -301,6 +303,7 @@ struct MatchParams {
     int P;                     // pixels per block (power of two, divides HW)
     float* gg_scratch;         // [B][match_scratch_floats(C)]: rolled descriptor of the small-C register form / Gm, Mk of the MFMA form (null = LDS form only)
     int prep_done;             // 1: launch_match_prep already ran on these parameters (launch_match then skips its preparation launch)
+    int no_wide;               // 1: never the latency forms (sixteen waves per workgroup / four waves per 64 pixels) - CCVPE_MATCH_WIDE=0, read per plan
 };
 void launch_match(const MatchParams& p, hipStream_t s);
 // The preparation launch alone (rolled descriptor / Gm, Mk into gg_scratch): it depends on the ground descriptor only, so a plan may issue it

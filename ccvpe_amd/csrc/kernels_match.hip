@@ -148,11 +148,19 @@ __global__ __launch_bounds__(256) void match_prep_kernel(const MatchParams p, fl
     match_prep_body(p, gg, red);
 }
 
-template <int C>
+// RG = 1: a thread per pixel walks all rolls.  RG = 4 (latency plans, round 4): the four WAVES of a workgroup share 64 pixels and take
+// every fourth roll each (the roll - and with it the address of the rolled descriptor - stays wave-uniform: scalar loads) - level 5 at
+// batch 1 is 16384 pixels = one wave per CU walking 20 rolls x 80 channels (24 us); the maximum over the rolls meets in LDS (order-free),
+// the descriptor copy is shared between the four waves.
+template <int C, int RG>
 __global__ __launch_bounds__(256) void match_small_kernel(const MatchParams p, const float* __restrict__ gg) {
+    __shared__ float bests[RG > 1 ? 256 : 1];
     const int b = blockIdx.y;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= p.HW) return;
+    const int rg = RG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int pix_raw = RG == 1 ? blockIdx.x * 256 + (int)threadIdx.x : blockIdx.x * 64 + ((int)threadIdx.x & 63);
+    if (RG == 1 && pix_raw >= p.HW) return;
+    const bool live = pix_raw < p.HW;          // (RG > 1: everybody reaches the barrier; a lane past the image works on the last pixel and stores nothing)
+    const int pix = live ? pix_raw : p.HW - 1;
     const float* xg = p.x + ((size_t)b * p.HW + pix) * p.x_ld;
     float x[C];
 #pragma unroll
@@ -167,8 +175,8 @@ __global__ __launch_bounds__(256) void match_small_kernel(const MatchParams p, c
     const float gnorm = gb[4 * C];
     const bool full = p.L == C;
     float best = -INFINITY;
-    for (int r = 0; r < p.R; ++r) {
-        const int base = C - p.shift[r];          // wave-uniform
+    for (int r = rg; r < p.R; r += RG) {
+        const int base = C - p.shift[r];          // wave-uniform (RG = 1)
         const float* gr = gb + base;
         float dot = 0.f;
 #pragma unroll
@@ -181,16 +189,26 @@ __global__ __launch_bounds__(256) void match_small_kernel(const MatchParams p, c
             for (int j = 0; j < C; ++j) n2 = fmaf(x[j] * x[j], mr[j], n2);
         }
         const float sc = dot / (sqrtf(n2) * gnorm);
-        if (p.ms) p.ms[((size_t)b * p.R + r) * p.HW + pix] = sc;
+        if (p.ms && live) p.ms[((size_t)b * p.R + r) * p.HW + pix] = sc;
         if ((p.inmax >> r) & 1u) best = fmaxf(best, sc);
+    }
+    if (RG > 1) {
+        bests[threadIdx.x] = best;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < RG; ++w) best = fmaxf(best, bests[w * 64 + (threadIdx.x & 63)]);
+        if (!live) return;
     }
     const float inv = 1.f / fmaxf(sqrtf(n2full), 1e-12f);
     float* o = p.cat_max + ((size_t)b * p.HW + pix) * p.cat_max_ld;
-    *reinterpret_cast<float4*>(o) = make_float4(best, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(o + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rg == 0) {
+        *reinterpret_cast<float4*>(o) = make_float4(best, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int c4 = 0; c4 < C / 4; ++c4)
-        *reinterpret_cast<float4*>(o + 8 + c4 * 4) = make_float4(x[c4 * 4] * inv, x[c4 * 4 + 1] * inv, x[c4 * 4 + 2] * inv, x[c4 * 4 + 3] * inv);
+        if (RG == 1 || (c4 & (RG - 1)) == rg)
+            *reinterpret_cast<float4*>(o + 8 + c4 * 4) = make_float4(x[c4 * 4] * inv, x[c4 * 4 + 1] * inv, x[c4 * 4 + 2] * inv, x[c4 * 4 + 3] * inv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -250,13 +268,19 @@ __global__ __launch_bounds__(256) void match_prep_all_kernel(const MatchPrepAll 
     else if (a.form[z] == 1 && blockIdx.y == 0) match_prep_body(a.p[z], a.p[z].gg_scratch, red);
 }
 
-__global__ __launch_bounds__(256) void match_mfma_kernel(const MatchParams p, const float* __restrict__ gm) {
+// NW = 4 waves per workgroup, or 16 in latency plans (round 4): level 1 at batch 1 is FOUR workgroups whose waves walked 20 chunks of
+// 1280 channels with one trip to memory per chunk (28 us); sixteen waves with their <= 5 chunks' Gm / Mk fragments requested at once
+// make it one trip.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void match_mfma_kernel(const MatchParams p, const float* __restrict__ gm) {
+    constexpr int NT = 64 * NW;
+    constexpr int UB = 5;                  // chunks whose fragments a wave requests at once
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int C = p.C, R = p.R;
     const int ldx = C + 4;                 // 16-byte rows, 4 mod 32 floats (C % 32 == 0): conflict-free b128 reads across the 16 pixels
     float* xs = smem;                      // [16][C + 4]
-    float* red = xs + 16 * ldx;            // [4 waves][2 (S, N2)][2 tiles][64 lanes][4]
-    float* sc = red + 4 * 2 * 2 * 256;     // [32][16] final scores (row 31: squared full norm)
+    float* red = xs + 16 * ldx;            // [NW waves][2 (S, N2)][2 tiles][64 lanes][4]
+    float* sc = red + NW * 2 * 2 * 256;    // [32][16] final scores (row 31: squared full norm)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blocks_per_sample = p.HW >> 4;
     const int b = blockIdx.x / blocks_per_sample;
@@ -264,35 +288,47 @@ __global__ __launch_bounds__(256) void match_mfma_kernel(const MatchParams p, co
     const float* xg = p.x + ((size_t)b * p.HW + pix0) * p.x_ld;
 
     const int c4n = C >> 2;
-    for (int i = tid; i < 16 * c4n; i += 256) {
+    for (int i = tid; i < 16 * c4n; i += NT) {
         const int pp = i / c4n, c4 = i - pp * c4n;
         *reinterpret_cast<f32x4m*>(xs + pp * ldx + c4 * 4) = *reinterpret_cast<const f32x4m*>(xg + (size_t)pp * p.x_ld + c4 * 4);
     }
-    __syncthreads();
 
     const size_t per = (size_t)C * 32;
     const float* G = gm + (size_t)b * (2 * per + 4);
     const float* M = G + per;
     const float gnorm = G[2 * per];
-    // wave w owns chunks w, w + 4, ... of 16 channels
+    // wave w owns chunks w, w + NW, ... of 16 channels; the Gm / Mk fragments of UB chunks are requested together - and, the first
+    // time, before the barrier that ends the staging of x (a chunk past the last re-reads the last one and multiplies it with zeros)
     f32x4m accS[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accN[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const float* ap = xs + (lane & 15) * ldx + 4 * (lane >> 4);
     const int nchunks = C >> 4;
-    for (int ch = wave; ch < nchunks; ch += 4) {
-        const f32x4m a = *reinterpret_cast<const f32x4m*>(ap + ch * 16);
-        const f32x4m a2 = a * a;
-        const f32x4m g0 = *reinterpret_cast<const f32x4m*>(G + ((size_t)(ch * 2 + 0) * 64 + lane) * 4);
-        const f32x4m g1 = *reinterpret_cast<const f32x4m*>(G + ((size_t)(ch * 2 + 1) * 64 + lane) * 4);
-        const f32x4m m0 = *reinterpret_cast<const f32x4m*>(M + ((size_t)(ch * 2 + 0) * 64 + lane) * 4);
-        const f32x4m m1 = *reinterpret_cast<const f32x4m*>(M + ((size_t)(ch * 2 + 1) * 64 + lane) * 4);
+    for (int ch0 = wave; ch0 < nchunks; ch0 += NW * UB) {
+        f32x4m g0[UB], g1[UB], m0[UB], m1[UB];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            accS[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], g0[e], accS[0], 0, 0, 0);
-            accS[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], g1[e], accS[1], 0, 0, 0);
-            accN[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[e], m0[e], accN[0], 0, 0, 0);
-            accN[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[e], m1[e], accN[1], 0, 0, 0);
+        for (int u = 0; u < UB; ++u) {
+            const int ch = min(ch0 + u * NW, nchunks - 1);
+            g0[u] = *reinterpret_cast<const f32x4m*>(G + ((size_t)(ch * 2 + 0) * 64 + lane) * 4);
+            g1[u] = *reinterpret_cast<const f32x4m*>(G + ((size_t)(ch * 2 + 1) * 64 + lane) * 4);
+            m0[u] = *reinterpret_cast<const f32x4m*>(M + ((size_t)(ch * 2 + 0) * 64 + lane) * 4);
+            m1[u] = *reinterpret_cast<const f32x4m*>(M + ((size_t)(ch * 2 + 1) * 64 + lane) * 4);
+        }
+        if (ch0 == wave) __syncthreads();   // (uniform: every wave's first batch) x is staged
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int ch = ch0 + u * NW;
+            f32x4m a = *reinterpret_cast<const f32x4m*>(ap + min(ch, nchunks - 1) * 16);
+            if (ch >= nchunks) a = f32x4m{0.f, 0.f, 0.f, 0.f};
+            const f32x4m a2 = a * a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                accS[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], g0[u][e], accS[0], 0, 0, 0);
+                accS[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], g1[u][e], accS[1], 0, 0, 0);
+                accN[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[e], m0[u][e], accN[0], 0, 0, 0);
+                accN[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[e], m1[u][e], accN[1], 0, 0, 0);
+            }
         }
     }
+    if (wave >= nchunks) __syncthreads();   // (a wave without chunks never entered the loop: its share of the staging barrier)
     // partial sums -> LDS; accumulator element i of lane l is (pixel 4*(l>>4) + i, roll 16*t + (l&15))
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -304,10 +340,11 @@ __global__ __launch_bounds__(256) void match_mfma_kernel(const MatchParams p, co
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int idx = tid + k * 256;
+            if (NW > 4 && tid >= 256) break;
             const int t = idx >> 8, l = (idx >> 2) & 63, i = idx & 3;
             float s = 0.f, n2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 s += red[(((w * 2 + 0) * 2 + t) * 64 + l) * 4 + i];
                 n2 += red[(((w * 2 + 1) * 2 + t) * 64 + l) * 4 + i];
             }
@@ -318,13 +355,13 @@ __global__ __launch_bounds__(256) void match_mfma_kernel(const MatchParams p, co
     __syncthreads();
 
     if (p.ms) {
-        for (int it = tid; it < 16 * R; it += 256) {
+        for (int it = tid; it < 16 * R; it += NT) {
             const int pp = it & 15, r = it >> 4;
             p.ms[((size_t)b * R + r) * p.HW + pix0 + pp] = sc[r * 16 + pp];
         }
     }
     if (p.cat_max) {
-        for (int it = tid; it < 16 * 8; it += 256) {
+        for (int it = tid; it < 16 * 8; it += NT) {
             const int pp = it >> 3, ch = it & 7;
             float v = 0.f;
             if (ch == 0) {
@@ -336,12 +373,12 @@ __global__ __launch_bounds__(256) void match_mfma_kernel(const MatchParams p, co
         }
     }
     if (p.cat_all) {
-        for (int it = tid; it < 16 * p.rpad; it += 256) {
+        for (int it = tid; it < 16 * p.rpad; it += NT) {
             const int pp = it / p.rpad, ch = it - pp * p.rpad;
             p.cat_all[((size_t)b * p.HW + pix0 + pp) * p.cat_all_ld + ch] = ch < R ? sc[ch * 16 + pp] : 0.f;
         }
     }
-    for (int i = tid; i < 16 * c4n; i += 256) {
+    for (int i = tid; i < 16 * c4n; i += NT) {
         const int pp = i / c4n, c4 = i - pp * c4n;
         const float inv = 1.f / fmaxf(sqrtf(sc[31 * 16 + pp]), 1e-12f);
         const f32x4m v = *reinterpret_cast<const f32x4m*>(xs + pp * ldx + c4 * 4) * inv;
@@ -393,17 +430,31 @@ void launch_match(const MatchParams& p, hipStream_t s) {
     if (match_use_mfma(p)) {
         if (!p.prep_done) CCVPE_LAUNCH(match_mfma_prep_kernel, dim3(p.B, 8), dim3(256), 0, s, p, p.gg_scratch);
         const size_t lds = ((size_t)16 * (p.C + 4) + 4 * 2 * 2 * 256 + 32 * 16) * sizeof(float);
+        const size_t lds16 = ((size_t)16 * (p.C + 4) + 16 * 2 * 2 * 256 + 32 * 16) * sizeof(float);
+        if (!p.no_wide && p.C >= 640 && p.B * (p.HW >> 4) <= 128 && lds16 <= 158 * 1024) {   // latency plans, >= 10 chunks per wave of four: sixteen waves per workgroup (C = 320: 11.7 -> 14.4 us, left with four)
+            static LdsAttr attr16;
+            ensure_dynamic_lds(attr16, reinterpret_cast<const void*>(match_mfma_kernel<16>), lds16);
+            CCVPE_LAUNCH(match_mfma_kernel<16>, dim3(p.B * (p.HW >> 4)), dim3(1024), lds16, s, p, (const float*)p.gg_scratch);
+            return;
+        }
         static LdsAttr attr;
-        if (lds > 64 * 1024) ensure_dynamic_lds(attr, reinterpret_cast<const void*>(match_mfma_kernel), lds);
-        CCVPE_LAUNCH(match_mfma_kernel, dim3(p.B * (p.HW >> 4)), dim3(256), lds, s, p, (const float*)p.gg_scratch);
+        if (lds > 64 * 1024) ensure_dynamic_lds(attr, reinterpret_cast<const void*>(match_mfma_kernel<4>), lds);
+        CCVPE_LAUNCH(match_mfma_kernel<4>, dim3(p.B * (p.HW >> 4)), dim3(256), lds, s, p, (const float*)p.gg_scratch);
         return;
     }
     if (p.gg_scratch && match_small_supported(p)) {
         if (!p.prep_done) CCVPE_LAUNCH(match_prep_kernel, dim3(p.B), dim3(256), 0, s, p, p.gg_scratch);
+        if (!p.no_wide && (long long)p.B * ((p.HW + 255) / 256) <= 256) {   // latency plans: four lanes per pixel
+            dim3 grid((p.HW + 63) / 64, p.B);
+            if (p.C == 32) CCVPE_LAUNCH((match_small_kernel<32, 4>), grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
+            else if (p.C == 40) CCVPE_LAUNCH((match_small_kernel<40, 4>), grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
+            else CCVPE_LAUNCH((match_small_kernel<80, 4>), grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
+            return;
+        }
         dim3 grid((p.HW + 255) / 256, p.B);
-        if (p.C == 32) CCVPE_LAUNCH(match_small_kernel<32>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
-        else if (p.C == 40) CCVPE_LAUNCH(match_small_kernel<40>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
-        else CCVPE_LAUNCH(match_small_kernel<80>, grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
+        if (p.C == 32) CCVPE_LAUNCH((match_small_kernel<32, 1>), grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
+        else if (p.C == 40) CCVPE_LAUNCH((match_small_kernel<40, 1>), grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
+        else CCVPE_LAUNCH((match_small_kernel<80, 1>), grid, dim3(256), 0, s, p, (const float*)p.gg_scratch);
         return;
     }
     size_t lds = ((size_t)p.P * (p.C + 1) + ((p.L + 3) & ~3) + (size_t)(p.R + 1) * p.P + 4) * sizeof(float);

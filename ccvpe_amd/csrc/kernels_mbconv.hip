@@ -405,10 +405,9 @@ int mbconv_front_ticket_rows(const MbFrontParams& p) {
 // ... and how many workgroups share a tile group's channels (each draws a ticket: SeTicket::per_sample = rows x this).  More than one only
 // in latency plans: the launch then has ~384 workgroups of four waves, three per CU beside the other encoder's
 int mbconv_front_ticket_split(const MbFrontParams& p) {
-    static const bool off = getenv("CCVPE_FRONT_SPLIT") != nullptr && std::atoi(getenv("CCVPE_FRONT_SPLIT")) == 0;
     const int rows = mbconv_front_ticket_rows(p);
-    if (rows == 0 || off || (long long)rows * p.B > 192) return 1;
-    return std::max(1, std::min(p.mid / 16, 384 / (rows * p.B)));
+    if (rows == 0 || p.spread <= 0 || (long long)rows * p.B > 192) return 1;
+    return std::max(1, std::min(p.mid / 16, 3 * p.spread / (rows * p.B)));   // (four-wave workgroups: three fit a CU)
 }
 
 void launch_mbconv_front(const MbFrontParams& p, hipStream_t s) {

@@ -442,7 +442,8 @@ static bool img_plan(const MbFrontParams& p, ImgPlan& pl) {
 // several CUs: the halo rows are expanded twice, the chip has the room.  Taken when the items still fit the chip in one round and a strip
 // reads at least a fifth fewer rows than the plan above.
 static void img_plan_spread(const MbFrontParams& p, ImgPlan& pl) {
-    static const int cap_items = getenv("CCVPE_IMG_SPREAD") != nullptr ? std::atoi(getenv("CCVPE_IMG_SPREAD")) : 128;   // items a launch may spread to - half the chip: the other stream runs the other encoder's front beside it (256: 1.25, 192: 1.22, 128: 1.20 ms per frame, 0 = off: 1.27)
+    const int cap_items = p.spread;   // items a launch may spread to - half the chip by default: the other stream runs the other encoder's front
+                                      // beside it (256: 1.25, 192: 1.22, 128: 1.20 ms per batch-1 frame, 0 = off: 1.27)
     const int chunks = p.mid / 16, kch = p.cinp / 16;
     if ((long long)p.B * pl.q.NST * chunks > cap_items / 2) return;
     const size_t cap = 158 * 1024;

@@ -358,6 +358,35 @@ def test_fused_stem_and_block0_depthwise_agree_with_separate_launches(name, monk
         assert (a - b).abs().max().item() <= 1e-4 * max(a.abs().max().item(), 1e-30), gu.OUTPUT_NAMES[i]
 
 
+@pytest.mark.parametrize("name,batch", [("vigor_prior180_circ", 1), ("oxford", 1), ("kitti", 2), ("vigor_prior72_fov108", 1)])
+def test_latency_plan_forms_agree_with_throughput_forms(name, batch, monkeypatch):
+    """Round 4, latency plans (batch <= 4): the fused MBConv fronts cut their work finer so that a block's 15-72 chunks spread over
+    the chip (more strips of the image-resident form - halo rows expanded twice -, channel ranges per tile group of the wave form) and
+    the matching levels run sixteen waves per workgroup / four waves per 64 pixels.  Against the same plan with the batch-32 forms
+    (CCVPE_FRONT_SPREAD=0, CCVPE_MATCH_WIDE=0): the same numbers up to the order of the pooling / channel sums, and the same bits on
+    every repeat."""
+    cfg = gu.CONFIGS[name]
+    g, s = inputs(cfg, batch=batch)
+    monkeypatch.setenv("CCVPE_FRONT_SPREAD", "0")
+    monkeypatch.setenv("CCVPE_MATCH_WIDE", "0")
+    ref = [t.clone() for t in build_model(cfg)(g, s)]
+    monkeypatch.delenv("CCVPE_FRONT_SPREAD")
+    monkeypatch.delenv("CCVPE_MATCH_WIDE")
+    m = build_model(cfg)
+    out = [t.clone() for t in m(g, s)]
+    mag = raw_ori_magnitude(cfg, g, s)
+    for i, (a, b) in enumerate(zip(ref, out)):
+        if i == 2:   # ori: weighted by the un-normalised magnitude
+            assert ori_weighted_error(a, b, mag) <= 1e-4, "ori"
+            continue
+        assert (a - b).abs().max().item() <= 1e-4 * max(a.abs().max().item(), 1e-30), gu.OUTPUT_NAMES[i]
+    for _ in range(3):
+        again = m(g, s)
+        torch.cuda.synchronize()
+        for a, b in zip(out, again):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("name,batch,prologue", [("vigor_prior180_circ", 3, 0), ("kitti", 2, 0), ("oxford", 5, 0), ("vigor_prior72_fov108", 32, 0),
                                                  ("vigor_prior180_circ", 2, 1), ("oxford", 1, 1)])
 def test_squeeze_excite_ticket_agrees_with_separate_launches(name, batch, prologue, monkeypatch):
