@@ -109,18 +109,21 @@ __device__ __forceinline__ float se_column_sum(const float* base, int ld, int co
 // independent 16-byte loads in flight).  Split in two so that the first batch can be requested early: se_excite_fetch before the squeezed
 // vector exists, se_excite_apply once it is in LDS.
 template <int JB>
-struct SeExciteRegs { tk_f32x4 w[JB]; };
+struct SeExciteRegs { tk_f32x4 w[JB]; tk_f32x4 b2; float b1; };   // + the two biases this thread will need: every load that waits behind a
+                                                                     //   barrier of the combining step is one more trip to memory on the launch's tail
 template <int NT, int JB>
 __device__ __forceinline__ void se_excite_fetch(const SeTicket& t, SeExciteRegs<JB>& r) {
     const int c = min((int)threadIdx.x * 4, t.C - 4);      // (threads past the last channel quad re-read it: no branch around the loads)
 #pragma unroll
     for (int u = 0; u < JB; ++u) r.w[u] = *reinterpret_cast<const tk_f32x4*>(t.w2 + (size_t)min(u, t.SQ - 1) * t.C + c);
+    r.b2 = *reinterpret_cast<const tk_f32x4*>(t.b2 + c);
+    r.b1 = t.b1[min((int)threadIdx.x, t.SQ - 1)];
 }
 template <int NT, int JB>
 __device__ __forceinline__ void se_excite_apply(const SeTicket& t, int b, const float* sq, SeExciteRegs<JB>& r) {
     bool first = true;
     for (int c = threadIdx.x * 4; c < t.C; c += NT * 4) {
-        tk_f32x4 a = *reinterpret_cast<const tk_f32x4*>(t.b2 + c);
+        tk_f32x4 a = first ? r.b2 : *reinterpret_cast<const tk_f32x4*>(t.b2 + c);
         for (int j0 = 0; j0 < t.SQ; j0 += JB) {
             if (!first) {
 #pragma unroll
@@ -184,7 +187,7 @@ __device__ __forceinline__ void se_finish_jb(const SeTicket& t, int b, float* sc
         if (tid < t.SQ) {
             float a = 0.f;
             for (int k = 0; k < c4n; ++k) a += part[tid * c4n + k];
-            sq[tid] = se_swish(a + t.b1[tid]);
+            sq[tid] = se_swish(a + er.b1);
         }
     } else {   // wide blocks without the distributed squeeze: wave w owns outputs w, w + NT / 64, ...
         const int lane = tid & 63, wave = tid >> 6;
@@ -227,7 +230,7 @@ __device__ __forceinline__ void se_finish_parts_jb(const SeTicket& t, int b, flo
     if (tid < t.SQ) {
         float v = 0.f;
         for (int g2 = 0; g2 < G; ++g2) v += part[g2 * t.SQ + tid];
-        sq[tid] = se_swish(v * t.inv_hw + t.b1[tid]);
+        sq[tid] = se_swish(v * t.inv_hw + er.b1);
     }
     __syncthreads();
     se_excite_apply<NT, JB>(t, b, sq, er);
@@ -240,7 +243,7 @@ __device__ __forceinline__ void se_finish_parts(const SeTicket& t, int b, float*
 // Latency plans (the launch's workgroups do not even fill the chip once: batch <= 4): a workgroup whose items all belong to ONE sample
 // draws its ticket behind its loop, and requests the excite weights BEFORE it knows whether the ticket is the last one - the request
 // then travels under the store drain, the ticket's round trip and the acquire instead of behind them.  All SQ rows at once (SE_JB_SPEC).
-static constexpr int SE_JB_SPEC = 32;
+static constexpr int SE_JB_SPEC = 32;   // (48 - every row of the widest blocks - spills: 192 registers of weights)
 #ifndef CCVPE_SE_CLOCK
 #define CCVPE_SE_CLOCK 0   // dev builds (tools/build_variant.sh): 1 = the last arriver stamps s_memrealtime (100 MHz) along the combining step
 #endif
