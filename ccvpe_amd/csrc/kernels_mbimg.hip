@@ -445,7 +445,7 @@ static void img_plan_spread(const MbFrontParams& p, ImgPlan& pl) {
     const int cap_items = p.spread;   // items a launch may spread to - half the chip by default: the other stream runs the other encoder's front
                                       // beside it (256: 1.25, 192: 1.22, 128: 1.20 ms per batch-1 frame, 0 = off: 1.27)
     const int chunks = p.mid / 16, kch = p.cinp / 16;
-    if ((long long)p.B * pl.q.NST * chunks > cap_items / 2) return;
+    if ((long long)p.B * pl.q.NST * chunks >= cap_items) return;
     const size_t cap = 158 * 1024;
     int best_rows = std::min(p.H, (pl.q.RO - 1) * p.s + p.k);
     for (int nst = pl.q.NST + 1; nst <= p.OH; ++nst) {
