@@ -211,7 +211,6 @@ struct Op {
 struct TapInfo { Tensor t; int coff; int C; };
 
 struct Plan {
-    int px_grd = 0, px_sat = 0;   // input pixels of the two encoders of this plan (plan_encoder: a front's share of the chip in latency plans)
     int B = 0, gh = 0, gw = 0;
     int mode = 0;                 // 0 full forward, 1 aerial encode only, 2 forward from a cached aerial encoding
     bool debug = false;

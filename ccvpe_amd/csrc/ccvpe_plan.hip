@@ -72,11 +72,13 @@ static void plan_encoder(ccvpe_handle_s* h, Plan& pl, const EncoderW& ew, bool i
         mp.B = B; mp.H = ch; mp.W = cw; mp.Cin = b.cin; mp.cinp = bw.exp_cinp; mp.mid = mid;
         mp.we = bw.exp_lin; mp.be = bw.expand.bias; mp.wd = bw.dw_w; mp.bd = bw.dw_b;
         mp.k = b.k; mp.s = b.s; mp.pad_t = lo; mp.pad_l = lo; mp.circular = circular; mp.OH = oh; mp.OW = ow;
-        // latency plans: the work items a front may spread to = this encoder's share of the 256 CUs by input pixels - the other encoder's
-        // fronts run beside it on the other stream (both at 128: 1.20 ms per VIGOR frame, both at 256: 1.25; the aerial encoder is the longer chain)
+        // latency plans: the work items a front may spread to = this encoder's share of the 256 CUs - the other encoder's fronts run beside
+        // it on the other stream (both at 128: 1.20 ms per VIGOR frame, both at 256: 1.25; the aerial encoder is the longer chain).  The aerial
+        // encoder takes 144 whatever it runs beside (its launches must not depend on the ground image: the aerial-only plan of
+        // ccvpe_encode_aerial returns the bits of the full forward), the ground encoder its share by input pixels against a 512 x 512 tile.
         {
-            const double share = (double)H * W / std::max(1.0, (double)pl.px_grd + (double)pl.px_sat);
-            const int dflt = std::max(64, std::min(224, (int)(256.0 * share / 16.0 + 0.5) * 16));
+            const double share = (double)H * W / ((double)H * W + (double)CCVPE_SAT_HW * CCVPE_SAT_HW);
+            const int dflt = is_grd ? std::max(64, std::min(128, (int)(256.0 * share / 16.0 + 0.5) * 16)) : 144;
             mp.spread = getenv("CCVPE_FRONT_SPREAD") ? std::atoi(getenv("CCVPE_FRONT_SPREAD")) : dflt;   // (read per plan: tests toggle it)
         }
         // small-spatial blocks: the whole expanded image of 16 channels lives in LDS (kernels_mbimg.hip); CCVPE_FUSE_MBCONV=0 / CCVPE_MBCONV_IMAGE=0 turn it off
@@ -321,7 +323,6 @@ int build_plan(ccvpe_handle_s* h, Plan& pl, int B, int gh, int gw, int mode) {
 
     // ---- encoders ----
     EncOut genc, senc;
-    pl.px_grd = gh * gw; pl.px_sat = CCVPE_SAT_HW * CCVPE_SAT_HW;
     plan_encoder(h, pl, h->grd_enc, true, B, gh, gw, h->cfg.circular_padding != 0, nullptr, genc, "grd");
     TapDst td[5];
     for (int t = 0; t < 5; ++t) {
@@ -599,7 +600,6 @@ static int build_aerial_plan(ccvpe_handle_s* h, Plan& pl, int B) {
     pl.B = B; pl.gh = 0; pl.gw = 0; pl.mode = 1; pl.debug = false;
     pl.scratch = pl.alloc(1, 1, 1, (int)Plan::SPLITK_FLOATS);
     EncOut senc;
-    pl.px_grd = 0; pl.px_sat = CCVPE_SAT_HW * CCVPE_SAT_HW;
     plan_encoder(h, pl, h->sat_enc, false, B, CCVPE_SAT_HW, CCVPE_SAT_HW, false, nullptr, senc, "sat");
     size_t coff[6];
     cache_layout(vs, B, coff);
