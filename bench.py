@@ -250,8 +250,7 @@ def main() -> int:
     def make_step(m, gg, ss, cc=None):
         def step():
             outs = m.forward_cached(gg, cc) if cc is not None else m(gg, ss)
-            post = m.postprocess(outs[1], outs[2])
-            rows = torch.stack([post["index"].to(torch.float32), post["prob"], post["cos"], post["sin"], post["angle_deg"]], dim=1)
+            rows = m.postprocess_rows(outs[1], outs[2])   # [B, 5] float rows written by the post-processing launch itself
             return D.gather_results(rows)
         return step
 

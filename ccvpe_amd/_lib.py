@@ -48,6 +48,7 @@ SYMBOLS = [
     ("ccvpe_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                 C.POINTER(Outputs), C.c_void_p]),
     ("ccvpe_postprocess", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("ccvpe_postprocess_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     ("ccvpe_eval_metrics", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     ("ccvpe_aerial_cache_bytes", C.c_size_t, [C.c_void_p, C.c_int32]),

@@ -108,6 +108,7 @@ int ccvpe_destroy(ccvpe_handle h) {
     (void)hipSetDevice(h->cfg.device);
     for (void* p : h->dev_allocs) (void)hipFree(p);
     if (h->arena) (void)hipFree(h->arena);
+    if (h->post_scratch) (void)hipFree(h->post_scratch);
     h->plans.clear();
     for (int k = 0; k < 2; ++k) if (h->snap[k]) (void)hipFree(h->snap[k]);
     if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
@@ -370,14 +371,40 @@ int ccvpe_profile_row_issued(ccvpe_handle h, int32_t i, double* issued_flops) {
     return 0;
 }
 
-int ccvpe_postprocess(ccvpe_handle h, const float* heatmap, const float* ori, int32_t batch, ccvpe_pose* poses, void* stream) {
-    if (!h || !heatmap || !ori || !poses || batch <= 0) return ccvpe_fail(CCVPE_EINVAL, "bad argument");
+// scratch of the post-processing launch: grows with the largest batch seen (the only synchronising step, once per size)
+static int ensure_post_scratch(ccvpe_handle_s* h, int batch) {
+    if (batch <= h->post_batch) return 0;
+    HIPCHK(hipDeviceSynchronize());   // a launch in flight may still use the old buffer
+    if (h->post_scratch) HIPCHK(hipFree(h->post_scratch));
+    h->post_scratch = nullptr; h->post_batch = 0;
+    const int cap = std::max(batch, 32);
+    void* d = nullptr;
+    if (hipMalloc(&d, postprocess_scratch_bytes(cap)) != hipSuccess) return ccvpe_fail(CCVPE_ENOMEM, "post-processing scratch");
+    HIPCHK(hipMemset(d, 0, postprocess_scratch_bytes(cap)));
+    HIPCHK(hipDeviceSynchronize());
+    h->post_scratch = d; h->post_batch = cap;
+    return 0;
+}
+
+static int postprocess_any(ccvpe_handle h, const float* heatmap, const float* ori, int32_t batch, ccvpe_pose* poses, float* rows, void* stream) {
+    if (!h || !heatmap || !ori || (!poses && !rows) || batch <= 0 || batch > PP_MAX_BATCH) return ccvpe_fail(CCVPE_EINVAL, "bad argument (batch 1 .. 4096)");
     HIPCHK(hipSetDevice(h->cfg.device));
     static_assert(sizeof(ccvpe_pose) == sizeof(PoseOut), "pose layout");
-    launch_postprocess(heatmap, ori, batch, CCVPE_OUT_HW * CCVPE_OUT_HW, reinterpret_cast<PoseOut*>(poses), (hipStream_t)stream);
+    if (int rc = ensure_post_scratch(h, batch)) return rc;
+    launch_postprocess(heatmap, ori, batch, CCVPE_OUT_HW * CCVPE_OUT_HW, reinterpret_cast<PoseOut*>(poses), rows, h->post_scratch, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ccvpe_fail(CCVPE_EHIP, "postprocess launch failed: %s", hipGetErrorString(e));
     return 0;
+}
+
+int ccvpe_postprocess(ccvpe_handle h, const float* heatmap, const float* ori, int32_t batch, ccvpe_pose* poses, void* stream) {
+    if (!poses) return ccvpe_fail(CCVPE_EINVAL, "bad argument");
+    return postprocess_any(h, heatmap, ori, batch, poses, nullptr, stream);
+}
+
+int ccvpe_postprocess_rows(ccvpe_handle h, const float* heatmap, const float* ori, int32_t batch, float* rows, void* stream) {
+    if (!rows) return ccvpe_fail(CCVPE_EINVAL, "bad argument");
+    return postprocess_any(h, heatmap, ori, batch, nullptr, rows, stream);
 }
 
 int ccvpe_eval_metrics(ccvpe_handle h, const ccvpe_pose* poses, const float* heatmap, int32_t batch, const int32_t* gt_index,

@@ -442,6 +442,8 @@ struct ccvpe_handle_s {
     bool tuning_lookup = true;    // false while a CCVPE_TUNE_* / CCVPE_NO_PW diagnostic switch is set
     float* arena = nullptr;
     size_t arena_floats = 0;
+    void* post_scratch = nullptr;   // launch_postprocess: partial pairs and ticket counters for post_batch samples
+    int post_batch = 0;
     // profiling rows of the last ccvpe_profile_forward
     struct Row { std::string name; float ms; double flops, bytes, issued; };
     std::vector<Row> prof;

@@ -157,7 +157,12 @@ int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
                 if (split > 1 && no_split) break;
                 if (split == 255 && (!conv_igemm_tile_is_wino4(t) || conv_igemm_tile_is_wino4x(t))) continue;
                 if (split > 1 && (split & (split - 1)) && !conv_igemm_tile_is_wino(t)) continue;
-                if (split > 1 && conv_igemm_tile_is_pw(t)) break;   // the pointwise persistent tiles keep K whole
+                // the latency form can split K (self-reducing, layers without a gate) but never wins: its workgroups are sixteen waves, the
+                // chip starts ~40 of them per us, and S times as many workgroups cost more than their shorter K runs save (tools/time_lat_gemm.py:
+                // level-6 transposed conv 18 / 25 / 41 / 73 us at S = 1 / 2 / 4 / 8).  CCVPE_TUNE_LAT_SPLIT=1 times them all the same.
+                static const bool lat_split_on = getenv("CCVPE_TUNE_LAT_SPLIT") != nullptr;
+                const bool lat_split = lat_split_on && conv_igemm_tile_proj_rt(t) >= 100 && op.gemm_m <= 256;
+                if (split > 1 && conv_igemm_tile_is_pw(t) && !lat_split) break;   // the pointwise persistent tiles keep K whole
                 if (split > 1 && split != 255) {   // split-K only where the grid underfills the chip and K is deep enough
                     // (the persistent Winograd grid also splits when the tile count is an awkward multiple of the
                     // 512 resident workgroups: 640 tiles = 1.25 per workgroup, 4 x 640 quarter-tiles = 5 each)
@@ -165,12 +170,13 @@ int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
                     if (blocks >= (wino ? 2048 : 512) || blocks * split > (wino ? 8192 : 2048) || nkt < 4 * split) break;
                     if ((size_t)split * op.gemm_m * op.gemm_n > Plan::SPLITK_FLOATS) break;
                 }
-                for (int fuse = 0; fuse < 2; ++fuse) {   // a split launch: with the reduce launch, and reducing itself (ticket.h) where the kernel can
+                for (int fuse = (split > 1 && conv_igemm_tile_is_pw(t)) ? 1 : 0; fuse < 2; ++fuse) {   // a split launch: with the reduce launch, and reducing itself (ticket.h) where the kernel can
                 if (fuse && (split <= 1 || split == 255 || !conv_igemm_tile_can_fuse_split(t) || pl.tickets == nullptr || getenv("CCVPE_TUNE_NO_FUSED_SPLIT"))) break;
                 const int cfg = t | ((fuse ? split + SPLIT_FUSED : split) << 8);
                 *op.tile = cfg;
                 op.fn(c);   // warm-up (also sets the dynamic-LDS attribute on first use)
                 if (split == 255 && (conv_igemm_last_tile() >> 8) != 255) break;   // tail split not applicable to this grid
+                if (split > 1 && conv_igemm_tile_is_pw(t) && ((conv_igemm_last_tile() >> 8) & 0xff) <= 1) break;   // (a gated layer: the launch kept K whole)
                 float ms = 1e30f;
                 for (int trial = 0; trial < 3; ++trial) {   // min of three timed pairs: one noisy sample must not pick the tile
                     HIPCHK(hipEventRecord(e0, nullptr));

@@ -378,7 +378,9 @@ int launch_resize(const ResizeParams& p, hipStream_t s);   // -1: down-scaling f
 void launch_scatter_channels(const float* src, int C, long long P, Dst d0, Dst d1, int ndst, hipStream_t s);
 
 struct PoseOut { int32_t index; float prob, cos_v, sin_v, angle_deg; };
-void launch_postprocess(const float* heat, const float* ori, int B, int n, PoseOut* out, hipStream_t s);
+static constexpr int PP_MAX_BATCH = 4096;           // samples per launch_postprocess call
+size_t postprocess_scratch_bytes(int B);            // partial (max, index) pairs + one ticket counter per sample (the counters zero before the first launch)
+void launch_postprocess(const float* heat, const float* ori, int B, int n, PoseOut* out, float* rows, void* scratch, hipStream_t s);   // rows != null: [B][5] floats instead of `out`
 
 struct MetricsOut { double pixel_distance, meter_distance, prob_at_gt, angle_pred_deg, angle_gt_deg, orientation_error_deg, longitudinal_m, lateral_m; };
 void launch_metrics(const PoseOut* pose, const float* heat, int B, int W, int n, const int* gt_index, const float* gt_cos_sin,

@@ -393,7 +393,8 @@ bool conv_igemm_tile_is_bf16x3(int tile) { tile &= 0xff; return tile > NTILES &&
 // kernels that can reduce their own split-K (split code SPLIT_FUSED + S): the fp32 implicit GEMM and the fused F(4x4) / F(2x2) Winograd kernels
 bool conv_igemm_tile_can_fuse_split(int tile) {
     tile &= 0xff;
-    return (tile >= 1 && tile <= NTILES) || (conv_igemm_tile_is_wino(tile) && !conv_igemm_tile_is_wino4p(tile) && !conv_igemm_tile_is_wino4x(tile));
+    return (tile >= 1 && tile <= NTILES) || (conv_igemm_tile_is_wino(tile) && !conv_igemm_tile_is_wino4p(tile) && !conv_igemm_tile_is_wino4x(tile)) ||
+           conv_igemm_tile_proj_rt(tile) >= 100;   // (the latency form of the deep-K GEMM: layers without a gate)
 }
 static void tile_dims(int tile, int& bm, int& bn) {
     if (tile >= 1 && tile <= NTILES) { bm = TILES[tile - 1].bm; bn = TILES[tile - 1].bn; }
@@ -522,7 +523,12 @@ int launch_conv_igemm(const ConvParams& p_in, int tile, hipStream_t s) {
     if (conv_igemm_tile_is_bf16x3(tile) && (p.w_hi == nullptr || p.w_lo == nullptr)) tile = 0;   // planes not packed: fp32 path
     if (conv_igemm_tile_is_wino(tile) && !conv_wino_tile_supported(p, tile)) tile = 0;
     if (conv_igemm_tile_is_pw(tile) && !conv_pw_tile_ok(pw_index(tile), p)) tile = 0;   // not a layer this pointwise tile takes
-    if (conv_igemm_tile_is_pw(tile)) splitk = 1;   // not a Winograd-shaped layer: implicit GEMM
+    if (conv_igemm_tile_is_pw(tile)) {   // the pointwise persistent tiles keep K whole; the latency form of the deep-K GEMM splits it only self-reducing, without a gate
+        const bool lat = conv_igemm_tile_proj_rt(tile) >= 100;
+        const int ct = lat ? std::max(1, (conv_igemm_tile_proj_rt(tile) - 100) % 10) : 1, rt = lat ? std::max(1, (conv_igemm_tile_proj_rt(tile) - 100) / 10) : 1;
+        const long long regions = (long long)((p.M + 16 * rt - 1) / (16 * rt)) * (((p.N + 15) / 16 + ct - 1) / ct);
+        if (!(lat && fused && p.gate == nullptr && p.se_rows == nullptr && p.partial != nullptr && regions <= CONV_TICKETS)) splitk = 1;
+    }
     if (tile < 1 || tile > conv_igemm_num_tiles()) tile = pick_tile(p);
     if (p.in_split) {   // pre-split bf16 input: only the bf16x3 kernels can read it
         if (p.w_hi == nullptr) return -1;

@@ -165,8 +165,13 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
     const int taps = p.KH * p.KW;
     const int spt = (p.Cin + 15) >> 4;                             // steps per tap
     const int nsteps = spt * taps;
-    const int per = (nsteps + PL_WAVES - 1) / PL_WAVES;
-    const int s_begin = min(wave * per, nsteps), s_end = min(s_begin + per, nsteps);
+    // self-reducing split-K (layers without a gate; igemm_common.h): gridDim.z workgroups share an output tile, each takes a run of steps,
+    // leaves its partial tile in its slab and draws a ticket - 64 rows x 1280 columns x K 5120 (the aerial descriptor conv at batch 1) are 80
+    // workgroups otherwise, each pulling 1.6 MB of operands through one CU
+    const int nz = (!GATE && p.splitk > 1) ? (int)gridDim.z : 1;
+    const int st_lo = nz > 1 ? (int)((long long)nsteps * blockIdx.z / nz) : 0, st_hi = nz > 1 ? (int)((long long)nsteps * (blockIdx.z + 1) / nz) : nsteps;
+    const int per = (st_hi - st_lo + PL_WAVES - 1) / PL_WAVES;
+    const int s_begin = min(st_lo + wave * per, st_hi), s_end = min(s_begin + per, st_hi);
     const int m0 = blockIdx.x * 16 * RTB;
     const int ct_all = (p.N + 15) >> 4, t0 = blockIdx.y * CTB;
 
@@ -332,10 +337,21 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
         const int n = (t0 + ct_w) * 16 + kq4;
         const int mo = m + 16 * rt_w;
         if (mo < p.M && n < p.N) {
+            if (nz > 1) {   // partial sums of this K slice -> its slab, write-through
+                float* dst = p.partial + ((size_t)blockIdx.z * p.M + mo) * p.N + n;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i] + (n + i < p.N ? p.bias[n + i] : 0.f), p.act);
-            emit_out4(p, mo, n, v);
+                for (int i = 0; i < 4; ++i)
+                    if (n + i < p.N) st_sc1(dst + i, v[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i] + (n + i < p.N ? p.bias[n + i] : 0.f), p.act);
+                emit_out4(p, mo, n, v);
+            }
         }
+    }
+    if (!GATE && nz > 1) {   // (uniform: every thread of the workgroup; the exchange area is dead behind the ticket's first barrier)
+        if (splitk_ticket(p, blockIdx.y * gridDim.x + blockIdx.x, reinterpret_cast<unsigned*>(smem)))
+            splitk_finish<64 * PL_WAVES>(p, m0, 1, 16 * RTB, 0, t0 * 16, 16 * CTB);
     }
 }
 
@@ -344,7 +360,8 @@ static int proj_lat_steps(const ConvParams& p) { return ((p.Cin + 15) / 16) * p.
 template <int CTB, bool GATE, int LS, bool SEP = false, int RTB = 1>
 static void launch_proj_lat2(const ConvParams& p, hipStream_t s) {
     constexpr size_t lds = ((size_t)PL_WAVES * CTB * RTB * 64 * 4 + (SEP ? 16 * 64 + 64 : 0)) * sizeof(float);
-    const dim3 grid((p.M + 16 * RTB - 1) / (16 * RTB), ((p.N + 15) / 16 + CTB - 1) / CTB);
+    dim3 grid((p.M + 16 * RTB - 1) / (16 * RTB), ((p.N + 15) / 16 + CTB - 1) / CTB);
+    if (!GATE && p.splitk > 1) grid.z = p.splitk;   // (launch_conv_igemm: only with ticket counters, a slab and <= CONV_TICKETS tiles)
     static LdsAttr attr;
     auto kern = conv_proj_lat_kernel<CTB, GATE, LS, SEP, RTB>;
     ensure_dynamic_lds(attr, reinterpret_cast<const void*>(kern), lds);

@@ -147,33 +147,39 @@ void launch_softmax(const SoftmaxParams& p, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // Post-processing: argmax (first maximal index, as numpy.argmax), prob, (cos, sin), angle in degrees.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void postprocess_kernel(const float* heat, const float* ori, int n, PoseOut* out) {
-    __shared__ float sv[16];
-    __shared__ int si[16];
-    const int b = blockIdx.x;
+// Round 4: one workgroup per sample scanned its 262144 values in sixteen rounds of loads - 16 trips to memory for ONE workgroup at batch 1
+// (17 us).  Now PP_CHUNKS workgroups per sample take 4096 values each (all their loads in one trip), leave (max, first index) per chunk
+// and draw a ticket (ticket.h); the workgroup that draws a sample's last one reduces the PP_CHUNKS pairs - the maximum with the
+// first-index tie-break does not depend on the order - and writes the pose.  `rows` != null: the same five numbers as floats
+// ([B][5]: index, prob, cos, sin, angle - the rows the data-parallel gather moves) instead of the ccvpe_pose records.
+static constexpr int PP_CHUNKS = 64;
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* heat, const float* ori, int n, PoseOut* out, float* rows, float* part, unsigned* tickets) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ unsigned flag;
+    const int b = blockIdx.y, c = blockIdx.x;
     const float* h = heat + (size_t)b * n;
+    const int lo = (int)((long long)n * c / PP_CHUNKS) & ~3, hi = c + 1 == PP_CHUNKS ? n : (int)((long long)n * (c + 1) / PP_CHUNKS) & ~3;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    // strictly greater keeps the first index per thread; 4 independent 16-byte loads in flight per round
-    const int n4 = ((reinterpret_cast<uintptr_t>(h) & 15) == 0) ? (n >> 2) : 0;
-    const float4* h4 = reinterpret_cast<const float4*>(h);
-    auto take = [&](float v, int i) { if (v > best) { best = v; bi = i; } };
-    int i = threadIdx.x;
-    for (; i + 3 * 1024 < n4; i += 4 * 1024) {
-        float4 v[4];
+    auto take = [&](float v, int i) { if (v > best) { best = v; bi = i; } };   // strictly greater keeps the first index per thread
+    if ((reinterpret_cast<uintptr_t>(h) & 15) == 0) {
+        const float4* h4 = reinterpret_cast<const float4*>(h);
+        const int q_lo = lo >> 2, q_hi = hi >> 2;
+        for (int i = q_lo + threadIdx.x; i < q_hi; i += 4 * 256) {   // four independent 16-byte loads in flight per round (one round at 512 x 512)
+            float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = h4[i + u * 1024];
+            for (int u = 0; u < 4; ++u) v[u] = i + u * 256 < q_hi ? h4[i + u * 256] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = (i + u * 1024) * 4;
-            take(v[u].x, e); take(v[u].y, e + 1); take(v[u].z, e + 2); take(v[u].w, e + 3);
+            for (int u = 0; u < 4; ++u) {
+                const int e = (i + u * 256) * 4;
+                take(v[u].x, e); take(v[u].y, e + 1); take(v[u].z, e + 2); take(v[u].w, e + 3);
+            }
         }
+        for (int j = (q_hi << 2) + threadIdx.x; j < hi; j += 256) take(h[j], j);
+    } else {
+        for (int j = lo + threadIdx.x; j < hi; j += 256) take(h[j], j);
     }
-    for (; i < n4; i += 1024) {
-        const float4 v = h4[i];
-        take(v.x, i * 4); take(v.y, i * 4 + 1); take(v.z, i * 4 + 2); take(v.w, i * 4 + 3);
-    }
-    for (int j = n4 * 4 + threadIdx.x; j < n; j += 1024) take(h[j], j);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float v2 = __shfl_xor(best, off);
@@ -183,22 +189,51 @@ __global__ __launch_bounds__(1024) void postprocess_kernel(const float* heat, co
     if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w)
+        for (int w = 1; w < 4; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-        const float c = ori[((size_t)b * 2 + 0) * n + bi];
-        const float s = ori[((size_t)b * 2 + 1) * n + bi];
-        float ang = acosf(fminf(fmaxf(c, -1.f), 1.f)) * 57.29577951308232f;
-        if (s < 0.f) { ang = fmodf(-ang, 360.f); if (ang < 0.f) ang += 360.f; }
-        out[b].index = bi;
-        out[b].prob = best;
-        out[b].cos_v = c;
-        out[b].sin_v = s;
-        out[b].angle_deg = ang;
+        st_sc1(part + ((size_t)b * PP_CHUNKS + c) * 2, best);
+        st_sc1(part + ((size_t)b * PP_CHUNKS + c) * 2 + 1, __int_as_float(bi));
+    }
+    if (!ticket_arrive(tickets + b, 1u, (unsigned)PP_CHUNKS, &flag)) return;
+    if (threadIdx.x < 64) {
+        best = -INFINITY; bi = 0x7fffffff;
+        for (int k = threadIdx.x; k < PP_CHUNKS; k += 64) {
+            const float v2 = ld_sc1(part + ((size_t)b * PP_CHUNKS + k) * 2);
+            const int i2 = __float_as_int(ld_sc1(part + ((size_t)b * PP_CHUNKS + k) * 2 + 1));
+            if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float v2 = __shfl_xor(best, off);
+            const int i2 = __shfl_xor(bi, off);
+            if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+        }
+        if (threadIdx.x == 0) {
+            const float cs = ori[((size_t)b * 2 + 0) * n + bi];
+            const float sn = ori[((size_t)b * 2 + 1) * n + bi];
+            float ang = acosf(fminf(fmaxf(cs, -1.f), 1.f)) * 57.29577951308232f;
+            if (sn < 0.f) { ang = fmodf(-ang, 360.f); if (ang < 0.f) ang += 360.f; }
+            if (rows) {
+                rows[b * 5 + 0] = (float)bi; rows[b * 5 + 1] = best; rows[b * 5 + 2] = cs; rows[b * 5 + 3] = sn; rows[b * 5 + 4] = ang;
+            } else {
+                out[b].index = bi;
+                out[b].prob = best;
+                out[b].cos_v = cs;
+                out[b].sin_v = sn;
+                out[b].angle_deg = ang;
+            }
+        }
     }
 }
 
-void launch_postprocess(const float* heat, const float* ori, int B, int n, PoseOut* out, hipStream_t s) {
-    CCVPE_LAUNCH(postprocess_kernel, dim3(B), dim3(1024), 0, s, heat, ori, n, out);
+// scratch = [PP_MAX_BATCH ticket counters][B x PP_CHUNKS (max, index) pairs]; the counters are zero before the first launch and every launch
+// leaves them at zero (a larger buffer serves a smaller batch: the counters do not move)
+size_t postprocess_scratch_bytes(int B) { return ((size_t)PP_MAX_BATCH + (size_t)B * PP_CHUNKS * 2) * sizeof(float); }
+
+void launch_postprocess(const float* heat, const float* ori, int B, int n, PoseOut* out, float* rows, void* scratch, hipStream_t s) {
+    unsigned* tickets = reinterpret_cast<unsigned*>(scratch);
+    float* part = reinterpret_cast<float*>(scratch) + PP_MAX_BATCH;
+    CCVPE_LAUNCH(postprocess_kernel, dim3(PP_CHUNKS, B), dim3(256), 0, s, heat, ori, n, out, rows, part, tickets);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -319,6 +319,19 @@ class _CVMBase(nn.Module):
         f = buf.view(torch.float32)
         return {"index": buf[:, 0].to(torch.int64), "prob": f[:, 1], "cos": f[:, 2], "sin": f[:, 3], "angle_deg": f[:, 4]}
 
+    def postprocess_rows(self, heatmap: torch.Tensor, ori: torch.Tensor) -> torch.Tensor:
+        """postprocess() as ONE float32 tensor [B, 5] = (index, prob, cos, sin, angle_deg): the 20-byte rows a data-parallel
+        evaluation gathers, written by the post-processing launch itself (no conversion / stack launches behind it)."""
+        B = heatmap.shape[0]
+        self._ensure_handle(heatmap.device)
+        rows = torch.empty((B, 5), dtype=torch.float32, device=heatmap.device)
+        stream = torch.cuda.current_stream(heatmap.device).cuda_stream
+        rc = _lib.load().ccvpe_postprocess_rows(self._handle, C.c_void_p(heatmap.contiguous().data_ptr()),
+                                                C.c_void_p(ori.contiguous().data_ptr()), B, C.c_void_p(rows.data_ptr()),
+                                                C.c_void_p(stream))
+        _lib.check(rc, "ccvpe_postprocess_rows")
+        return rows
+
     METRIC_FIELDS = ("pixel_distance", "meter_distance", "prob_at_gt", "angle_pred_deg", "angle_gt_deg", "orientation_error_deg",
                      "longitudinal_m", "lateral_m")
 

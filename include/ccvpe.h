@@ -155,6 +155,10 @@ int ccvpe_forward(ccvpe_handle h, const float* grd, int32_t grd_h, int32_t grd_w
 /* Device-side test-loop post-processing on forward outputs: poses[B] is DEVICE memory. */
 int ccvpe_postprocess(ccvpe_handle h, const float* heatmap, const float* ori, int32_t batch,
                       ccvpe_pose* poses, void* stream);
+/* The same five numbers per query as one float row - rows[B][5] = (index, prob, cos, sin, angle_deg), DEVICE memory: the 20-byte
+ * record a data-parallel evaluation gathers (train_VIGOR.py:297-316 keeps them in Python lists).  batch <= 4096. */
+int ccvpe_postprocess_rows(ccvpe_handle h, const float* heatmap, const float* ori, int32_t batch,
+                           float* rows, void* stream);
 
 /* Ground-truth side of the same test loop, on device: `poses` from ccvpe_postprocess, `gt_index[B]` = flat index of
  * argmax(gt map) (y*512 + x), `gt_cos_sin[B][2]` = ground-truth orientation at that pixel (NULL: no orientation error),

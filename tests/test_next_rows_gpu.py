@@ -86,6 +86,17 @@ def test_postprocess_argmax_ties_take_the_first_index_like_numpy():
     np.testing.assert_array_equal(idx, [4099, 4, 0, n - 1])
     np.testing.assert_array_equal(post["prob"].cpu().numpy(), flat.max(axis=1))
     np.testing.assert_allclose(post["angle_deg"].cpu().numpy(), want[4].numpy(), rtol=1e-5, atol=1e-3)
+    # the same five numbers as float rows (ccvpe_postprocess_rows: what the data-parallel gather moves), a larger batch than the scratch was
+    # sized for, then the small one again (the ticket counters of the scratch do not move), and the same bits on every repeat
+    ht, ot = torch.from_numpy(heat).cuda(), torch.from_numpy(ori).cuda()
+    rows = m.postprocess_rows(ht, ot)
+    for k, name in enumerate(("prob", "cos", "sin", "angle_deg")):
+        assert torch.equal(rows[:, k + 1], post[name]), name
+    np.testing.assert_array_equal(rows[:, 0].cpu().numpy(), idx.astype(np.float32))
+    big = m.postprocess_rows(ht.repeat(12, 1, 1, 1), ot.repeat(12, 1, 1, 1))
+    assert torch.equal(big, rows.repeat(12, 1))
+    for _ in range(3):
+        assert torch.equal(m.postprocess_rows(ht, ot), rows)
 
 
 def _resize_reference(img_u8, oh, ow, shift, crop_w):

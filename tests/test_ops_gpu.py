@@ -268,3 +268,11 @@ def test_latency_form_deep_k_gemm_matches_torch(shape):
         assert err <= 2e-5, f"{name}: {err:.3g}"
         again, _ = _lib.op_conv2d(x, w, b, stride, 0, 0, _tile_id(name))
         assert torch.equal(out, again)
+    # self-reducing split-K of the latency form (split code 64 + S): K slices on gridDim.z, slabs + ticket, the last slice sums in slice order
+    for name, S in (("conv_projl_1", 2), ("conv_projl_r4", 4), ("conv_projl_2", 8)):
+        out, _ = _lib.op_conv2d(x, w, b, stride, 0, 0, _tile_id(name) | ((64 + S) << 8))
+        err = (out - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-5, f"{name} split {S}: {err:.3g}"
+        for _ in range(3):
+            again, _ = _lib.op_conv2d(x, w, b, stride, 0, 0, _tile_id(name) | ((64 + S) << 8))
+            assert torch.equal(out, again)

@@ -21,8 +21,7 @@ for variant, cls, kw, fov in (("vigor_ori_prior", models.CVM_VIGOR_ori_prior, di
 
     def step():
         o = m(g, s)
-        post = m.postprocess(o[1], o[2])
-        return torch.stack([post["index"].to(torch.float32), post["prob"], post["cos"], post["sin"], post["angle_deg"]], dim=1)
+        return m.postprocess_rows(o[1], o[2])
 
     for _ in range(20):
         step()
