@@ -157,8 +157,8 @@ int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
                 if (split > 1 && no_split) break;
                 if (split == 255 && (!conv_igemm_tile_is_wino4(t) || conv_igemm_tile_is_wino4x(t))) continue;
                 if (split > 1 && (split & (split - 1)) && !conv_igemm_tile_is_wino(t)) continue;
-                // the latency form can split K (self-reducing, layers without a gate) but never wins: its workgroups are sixteen waves, the
-                // chip starts ~40 of them per us, and S times as many workgroups cost more than their shorter K runs save (tools/time_lat_gemm.py:
+                // the latency form can split K (self-reducing, layers without a gate) but never wins: a sixteen-wave workgroup is alone on its CU
+                // and lives ~6 us whatever its share of K, so S times as many workgroups are S times as many rounds (tools/time_lat_gemm.py:
                 // level-6 transposed conv 18 / 25 / 41 / 73 us at S = 1 / 2 / 4 / 8).  CCVPE_TUNE_LAT_SPLIT=1 times them all the same.
                 static const bool lat_split_on = getenv("CCVPE_TUNE_LAT_SPLIT") != nullptr;
                 const bool lat_split = lat_split_on && conv_igemm_tile_proj_rt(t) >= 100 && op.gemm_m <= 256;
