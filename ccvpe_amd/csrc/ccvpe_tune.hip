@@ -142,6 +142,11 @@ int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
                 const int rt = conv_igemm_tile_proj_rt(t);   // row tiles per workgroup; >= 100: the latency form (small M only)
                 if (!op.proj_ok || !conv_proj_has(rt, op.gemm_n) || getenv("CCVPE_NO_PW")) continue;
                 if (rt >= 100 && (op.gemm_m > 4096 || op.gemm_kpad > 10240)) continue;   // (conv_proj_supported has the exact rule)
+                // the multi-row forms (conv_projl_r2 / r4) win the level-6 transposed convs by 1 us when timed alone (17.7 against 18.8 us) and lose
+                // in the frame, where the two decoders run that layer at the same time: 2 x 256 sixteen-wave workgroups, one per CU - 31.7 us
+                // each in the traced frame against ~24 for the four-wave implicit GEMM.  CCVPE_TUNE_LAT_ROWS=1 times them all the same.
+                static const bool lat_rows = getenv("CCVPE_TUNE_LAT_ROWS") != nullptr;
+                if (rt > 104 && (!lat_rows || op.gemm_m > 1024)) continue;
             } else if (conv_igemm_tile_is_pw(t)) {
                 ConvParams qq{}; qq.M = 16; qq.N = 1 << 20;
                 const int bn = (int)(((long long)qq.N) / conv_igemm_tile_blocks(qq, t));   // the tile's column width
@@ -175,8 +180,10 @@ int autotune_plan(ccvpe_handle_s* h, Plan& pl, const std::vector<bool>* known) {
                 const int cfg = t | ((fuse ? split + SPLIT_FUSED : split) << 8);
                 *op.tile = cfg;
                 op.fn(c);   // warm-up (also sets the dynamic-LDS attribute on first use)
-                if (split == 255 && (conv_igemm_last_tile() >> 8) != 255) break;   // tail split not applicable to this grid
-                if (split > 1 && conv_igemm_tile_is_pw(t) && ((conv_igemm_last_tile() >> 8) & 0xff) <= 1) break;   // (a gated layer: the launch kept K whole)
+                const int ran = conv_igemm_last_tile();   // (tile | split code << 8 of the launch just issued; reading it clears it)
+                if ((ran & 0xff) != t) break;   // the launch did not take this tile (launch_conv_igemm fell back to its own pick): nothing to time under this name
+                if (split == 255 && (ran >> 8) != 255) break;   // tail split not applicable to this grid
+                if (split > 1 && conv_igemm_tile_is_pw(t) && ((ran >> 8) & 0xff) <= 1) break;   // (a gated layer: the launch kept K whole)
                 float ms = 1e30f;
                 for (int trial = 0; trial < 3; ++trial) {   // min of three timed pairs: one noisy sample must not pick the tile
                     HIPCHK(hipEventRecord(e0, nullptr));

@@ -143,11 +143,14 @@ static constexpr int PL_WAVES = 16;
 // descriptor conv k2s2 (models.py:471-482): four taps on disjoint pixels, K = (tap, channel), a lane keeps one base address per tap.
 // Channels are padded to 16 per tap (zero weights; the activation read runs into the next pixel's first channels - finite numbers - or
 // past the tensor - zeros).
-// SEP (GATE must be set too): the squeeze-excite gates are computed HERE.  All threads sum the front kernel's squeeze rows (a row of SQ
-// floats per work item, row order; G groups of SQ threads, the groups meet in LDS) -> sq[j] = swish(b1[j] + mean); then lane (kq, r) of
-// a wave holds channels 16 s + 4 kq .. + 3 of its steps' activations and takes the excite rows j = r, r + 16, ...: three 16-byte loads
-// per step for SQ = 48, a butterfly over the 16 lanes of a quad, a sigmoid - the gate quad lands in the lane that multiplies it into
-// its A fragment.  Every request (activations, weights, excite rows, squeeze rows) goes out before the first wait.
+// SEP (GATE must be set too): the squeeze-excite gates are computed HERE, once per workgroup, with ONE trip to memory for everything the
+// workgroup needs.  Requested together at the start: the front kernel's squeeze rows (a row of SQ floats per work item; G groups of SQ
+// threads take rows g, g + G, ...), both bias vectors, the excite matrix (thread = (channel quad q, third h of the SQ rows): <= 16 loads of
+// 16 bytes) and the activations of the wave's K steps.  Then, through LDS: row sums -> sq[j] = swish(b1[j] + mean) -> per-third partial
+// excite products -> gates[c] = sigmoid(b2 + the three thirds, in that order); the weight fragments are requested when the excite rows have
+// left their registers (L2 hits, under the last two barriers), and every wave reads the gate quads of its steps from LDS.  (The first
+// version - every wave computing the gates of its own K slice with a butterfly over 16 lanes - chained four trips: rows, late excite rows,
+// excite bias, activations: 20.9 us against 9.7 for the gated form.)
 // RTB > 1 (no gate): RTB row tiles per workgroup - a weight fragment serves RTB MFMAs and the layer's weights are read M / (16 RTB) times
 // instead of M / 16 times.  The level-6 transposed convs and the aerial descriptor conv at batch 1 (64 rows, 21-26 MB of weights) ran at
 // 1 TB/s with four row-tile workgroups per column tile on four different XCDs, each pulling the panel through its own L2.
@@ -156,7 +159,6 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
     static_assert(!SEP || GATE, "SEP computes what GATE multiplies");
     static_assert(RTB == 1 || !GATE, "one gate vector per row tile: the multi-row form is for the layers without a gate");
     constexpr unsigned OOB = 0x80000000u;
-    constexpr int SEJ = 3;                                         // excite rows per lane and step: SQ <= 16 * SEJ = 48 (EfficientNet-B0: <= 48)
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [16 waves][CTB][64 lanes][4]; SEP: group partials and sq[] first
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -202,32 +204,32 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
     for (int t = 0; t < CTB; ++t)
 #pragma unroll
         for (int r = 0; r < RTB; ++r) acc[t][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // SEP: this thread's share of the squeeze rows (requested first; summed behind the operand requests of the first group)
+    // SEP: this thread's share of the squeeze rows, of the excite matrix and the biases - requested first, together with the activations below
     const int se_g = SEP ? tid / max(p.se_sq, 1) : 0, se_j = SEP ? tid - se_g * p.se_sq : 0;
     const int se_G = SEP ? min(64 * PL_WAVES / max(p.se_sq, 1), 16) : 1;      // groups: rows g, g + G, ...
-    float se_b1v = 0.f;                                            // bias of squeeze output tid (requested with everything else)
-    constexpr int SEU = 6;                                         // squeeze rows per thread: <= 6 x 16 groups
-    float se_v[SEU];
+    float se_b1v = 0.f;                                            // bias of squeeze output tid
+    constexpr int SEU = 9;                                         // squeeze rows per thread: <= 9 x 16 groups
+    constexpr int SET = 8;                                         // excite rows per thread and pass: SQ <= 3 x 16 takes two passes (the 64 registers of one do not exist)
+    float se_v[SEP ? SEU : 1];
+    f32x4 se_w[SEP ? SET : 1], se_b2v = {0.f, 0.f, 0.f, 0.f};
+    const int c4n = p.Cin >> 2;
+    const int se_h = SEP ? tid / max(c4n, 1) : 0, se_q = SEP ? tid - se_h * c4n : 0;   // third of the SQ rows, channel quad
+    const int se_jt = SEP ? (p.se_sq + 2) / 3 : 0;                  // rows per third (<= 16)
+    const unsigned wv = (SEP && se_h < 3) ? (unsigned)((se_h * se_jt * p.Cin + 4 * se_q) * 4) : OOB;   // (rows past this third / past SQ: loaded or zero, never summed)
     if (SEP) {
-        // (buffer loads with 32-bit offsets: per-thread 64-bit addresses of six loads are twelve registers this kernel does not have)
+        // (buffer loads with 32-bit offsets: per-thread 64-bit addresses would be registers this kernel does not have)
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.se_rows) + (size_t)(m0 / ohw) * p.se_nrows * p.se_sq, 0,
                                                                                  (unsigned)((size_t)p.se_nrows * p.se_sq * 4), 0x00020000);   // (a row tile lies inside one sample: checked by the host)
+        // (one address register per thread, the step between a thread's loads rides in the scalar offset; rows past the last are past the
+        //  descriptor's range: zeros, no traffic)
+        const unsigned rv = se_g < se_G ? (unsigned)((se_g * p.se_sq + se_j) * 4) : OOB;
 #pragma unroll
-        for (int u = 0; u < SEU; ++u) {
-            const int r = se_g + u * se_G;
-            se_v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, (se_g < se_G && r < p.se_nrows) ? (unsigned)((r * p.se_sq + se_j) * 4) : OOB, 0, 0));
-        }
+        for (int u = 0; u < SEU; ++u) se_v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, rv, u * se_G * p.se_sq * 4, 0));
         const __amdgpu_buffer_rsrc_t b1_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.se_b1), 0, (unsigned)(p.se_sq * 4), 0x00020000);
         se_b1v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b1_rsrc, (unsigned)(tid * 4), 0, 0));   // (threads past SQ: out of range, zero)
-    }
-    // SEP, second batch of requests - behind the barriers of the squeeze sums: excite rows
-    // 32 .. 47 (blocks 12-15 only; out of range - no traffic - elsewhere).  The activations (L2: the front kernel just wrote them) follow
-    // step by step as the excite rows leave their registers: all four kinds in one batch needed more than the 128 registers a wave has
-    // with sixteen waves on a CU.
-#define CCVPE_PL_LATE_REQUESTS()                                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < LS; ++i) {                                                                                \
-        const int s_ = sg + i, j_ = (lane & 15) + 16 * (SEJ - 1);                                                                     \
-        ew[i][SEJ - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (s_ < s_end && j_ < p.se_sq) ? (unsigned)((j_ * p.Cin + kq4) * 4) : OOB, s_ * 64, 0)); \
+#pragma unroll
+        for (int u = 0; u < SET; ++u) se_w[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, wv, u * p.Cin * 4, 0));
+        se_b2v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b2_rsrc, se_h == 0 ? (unsigned)(16 * se_q) : OOB, 0, 0));
     }
     int sg = s_begin;
 #pragma unroll 1
@@ -235,7 +237,6 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
         // every operand of the group, requested at once (steps past s_end and column tiles past the layer's ask for out-of-range
         // offsets: zeros, no traffic)
         f32x4 a[LS][RTB], g[LS], w[LS][CTB];
-        f32x4 ew[SEP ? LS : 1][SEP ? SEJ : 1];
 #pragma unroll
         for (int i = 0; i < LS; ++i) {
             const int s = sg + i;
@@ -243,26 +244,24 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
             const int tap = (SEP || taps == 1) ? 0 : s / spt;        // (scalar: s is wave-uniform; SEP: one tap)
             const int sub = s - tap * spt;
             const int tap_off = (SEP || taps == 1) ? 0 : ((tap / p.KW) * p.W + tap % p.KW) * p.in_ld * 4;   // (scalar)
-            if (!SEP) {
 #pragma unroll
-                for (int r = 0; r < RTB; ++r) a[i][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, live ? a_row[r] : OOB, tap_off + sub * 64, 0));
+            for (int r = 0; r < RTB; ++r) a[i][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, live ? a_row[r] : OOB, tap_off + sub * 64, 0));
+            if (GATE && !SEP) g[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, live ? g_off : OOB, sub * 64, 0));
+            if (!SEP) {   // (SEP: the weight fragments follow once the excite rows have left their registers)
+#pragma unroll
+                for (int t = 0; t < CTB; ++t)
+                    w[i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (live && t0 + t < ct_all) ? w_lane : OOB, (s * ct_all + t0 + t) * 1024, 0));
             }
-            if (SEP) {
-#pragma unroll
-                for (int e = 0; e < SEJ - 1; ++e) {   // excite row j = (lane & 15) + 16 e at channels 16 s + 4 kq .. + 3 (rows 32 .. 47: below)
-                    const int j = (lane & 15) + 16 * e;
-                    ew[i][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (live && j < p.se_sq) ? (unsigned)((j * p.Cin + kq4) * 4) : OOB, sub * 64, 0));
-                }
-            } else if (GATE) g[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, live ? g_off : OOB, sub * 64, 0));
-#pragma unroll
-            for (int t = 0; t < CTB; ++t)
-                w[i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (live && t0 + t < ct_all) ? w_lane : OOB, (s * ct_all + t0 + t) * 1024, 0));
         }
         __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the requests between the MFMAs to save registers: one memory latency per step)
         if (SEP) {
-            float* part = smem + PL_WAVES * CTB * 256;               // [G][SQ] group sums, then sq[SQ]: behind the exchange area (a fast wave may
-            float* sq = part + 16 * 64;                              //  already write its partial sums while a slow one still reads sq)
-            if (sg == s_begin) {                                     // (uniform per wave; every wave has at least one group - see the launcher)
+            // LDS behind the exchange area (a fast wave may already write its partial sums while a slow one still reads the gates):
+            // [G][SQ] group sums | sq[64] | [3][Cin] per-third excite products | gates[Cin]
+            float* part = smem + PL_WAVES * CTB * 256;
+            float* sq = part + 16 * 64;
+            float* gpart = sq + 64;
+            float* gates = gpart + 3 * p.Cin;
+            {                                                        // (one group per wave: the launcher)
                 float sum = 0.f;
 #pragma unroll
                 for (int u = 0; u < SEU; ++u) sum += se_v[u];
@@ -275,33 +274,52 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
                     sq[tid] = v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
                 }
                 __syncthreads();
-            }
-            CCVPE_PL_LATE_REQUESTS();
-            float sqv[SEJ];
-#pragma unroll
-            for (int e = 0; e < SEJ; ++e) sqv[e] = (lane & 15) + 16 * e < p.se_sq ? sq[(lane & 15) + 16 * e] : 0.f;
-#pragma unroll
-            for (int i = 0; i < LS; ++i) {
                 f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < SEJ; ++e) z += ew[i][e] * sqv[e];
+                for (int u = 0; u < SET; ++u) {
+                    const int jj = se_h * se_jt + u;
+                    const float sv = (se_h < 3 && u < se_jt && jj < p.se_sq) ? sq[jj] : 0.f;
+                    z[0] = fmaf(se_w[u][0], sv, z[0]); z[1] = fmaf(se_w[u][1], sv, z[1]); z[2] = fmaf(se_w[u][2], sv, z[2]); z[3] = fmaf(se_w[u][3], sv, z[3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bool pass2 = se_jt > SET;                      // (uniform: the blocks with more than 24 squeezed channels; L2 hits - every workgroup reads this matrix)
+                if (pass2) {
 #pragma unroll
-                for (int off = 1; off < 16; off <<= 1)
+                    for (int u = 0; u < SET; ++u) se_w[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, wv, (SET + u) * p.Cin * 4, 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) z[c] += __shfl_xor(z[c], off);
+                for (int i = 0; i < LS; ++i) {                       // the weight fragments: L2 hits, under the two barriers below
+                    const int s = sg + i;
+#pragma unroll
+                    for (int t = 0; t < CTB; ++t)
+                        w[i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (s < s_end && t0 + t < ct_all) ? w_lane : OOB, (s * ct_all + t0 + t) * 1024, 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (pass2) {
+#pragma unroll
+                    for (int u = 0; u < SET; ++u) {
+                        const int jj = se_h * se_jt + SET + u;
+                        const float sv = (se_h < 3 && SET + u < se_jt && jj < p.se_sq) ? sq[jj] : 0.f;
+                        z[0] = fmaf(se_w[u][0], sv, z[0]); z[1] = fmaf(se_w[u][1], sv, z[1]); z[2] = fmaf(se_w[u][2], sv, z[2]); z[3] = fmaf(se_w[u][3], sv, z[3]);
+                    }
+                }
+                if (se_h < 3 && se_q < c4n) *reinterpret_cast<f32x4*>(gpart + se_h * p.Cin + 4 * se_q) = z;
+                __syncthreads();
+                if (se_h == 0 && se_q < c4n) {
+                    const f32x4 zz = se_b2v + *reinterpret_cast<const f32x4*>(gpart + 4 * se_q) + *reinterpret_cast<const f32x4*>(gpart + p.Cin + 4 * se_q) +
+                                     *reinterpret_cast<const f32x4*>(gpart + 2 * p.Cin + 4 * se_q);
+                    f32x4 gq;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gq[c] = 1.f / (1.f + __expf(-zz[c]));
+                    *reinterpret_cast<f32x4*>(gates + 4 * se_q) = gq;
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int i = 0; i < LS; ++i) {
                 const int s = sg + i;
-                const int sub = s < s_end ? s - (taps == 1 ? 0 : s / spt) * spt : 0;
-                const f32x4 b2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b2_rsrc, (unsigned)(kq4 * 4), sub * 64, 0));   // (past Cin: zeros; such a step's activations are zeros too)
-                // the gate multiplies the WEIGHT fragment (already here; lane (kq, n) holds the same four channels of both operands), so
-                // no gate registers wait for the activations: (w g) a instead of w (g a)
-                f32x4 gq;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) gq[c] = 1.f / (1.f + __expf(-(z[c] + b2[c])));
-#pragma unroll
-                for (int t = 0; t < CTB; ++t) w[i][t] *= gq;
-                __builtin_amdgcn_sched_barrier(0);
-                a[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, s < s_end ? a_row[0] : OOB, s * 64, 0));   // (SEP: one tap)
-                __builtin_amdgcn_sched_barrier(0);
+                if (s < s_end) a[i][0] *= *reinterpret_cast<const f32x4*>(gates + 16 * s + kq4);   // (channels 16 s + 4 kq .. + 3 of this lane's fragment)
             }
         }
 #pragma unroll
@@ -320,7 +338,6 @@ __global__ __launch_bounds__(64 * PL_WAVES) void conv_proj_lat_kernel(const Conv
         __builtin_amdgcn_sched_barrier(0);
         sg += LS;
     } while (sg < s_end);
-#undef CCVPE_PL_LATE_REQUESTS
     // ---- the sixteen K-partials meet in LDS; wave t < CTB x RTB adds (column tile, row tile) t in wave order and stores it ----
     constexpr int NTL = CTB * RTB;
     static_assert(NTL <= PL_WAVES, "one wave per tile of the workgroup in the epilogue");
@@ -359,7 +376,7 @@ static int proj_lat_steps(const ConvParams& p) { return ((p.Cin + 15) / 16) * p.
 
 template <int CTB, bool GATE, int LS, bool SEP = false, int RTB = 1>
 static void launch_proj_lat2(const ConvParams& p, hipStream_t s) {
-    constexpr size_t lds = ((size_t)PL_WAVES * CTB * RTB * 64 * 4 + (SEP ? 16 * 64 + 64 : 0)) * sizeof(float);
+    const size_t lds = ((size_t)PL_WAVES * CTB * RTB * 64 * 4 + (SEP ? 16 * 64 + 64 + 4 * (size_t)p.Cin : 0)) * sizeof(float);
     dim3 grid((p.M + 16 * RTB - 1) / (16 * RTB), ((p.N + 15) / 16 + CTB - 1) / CTB);
     if (!GATE && p.splitk > 1) grid.z = p.splitk;   // (launch_conv_igemm: only with ticket counters, a slab and <= CONV_TICKETS tiles)
     static LdsAttr attr;
@@ -405,8 +422,8 @@ bool conv_proj_supported(const ConvParams& p, int rt) {
         if (rt > 104 && (p.gate != nullptr || p.se_rows != nullptr || p.M < 16 * ((rt - 100) / 10) || p.M > 1024)) return false;   // the multi-row forms: no gate, at least one full workgroup of rows
         if (p.se_rows != nullptr) {   // gates computed in the prologue: one group per wave, every wave busy, a row tile inside one sample, <= 64 squeeze outputs
             const int steps = proj_lat_steps(p);
-            if (rt != 101 || !one || steps > PL_WAVES * 5 || p.se_sq > 48 || p.se_sq < 1 || p.se_nrows > 6 * std::min(1024 / p.se_sq, 16) ||
-                !(p.B == 1 || (p.OH * p.OW) % 16 == 0)) return false;
+            if (rt != 101 || !one || steps > PL_WAVES * 5 || p.se_sq > 48 || p.se_sq < 1 || p.se_nrows > 9 * std::min(1024 / p.se_sq, 16) ||
+                3 * (p.Cin / 4) > 64 * PL_WAVES || !(p.B == 1 || (p.OH * p.OW) % 16 == 0)) return false;
         }
         const int steps = proj_lat_steps(p);
         return steps <= PL_WAVES * 40;
