@@ -444,7 +444,7 @@ def main() -> int:
                 "algorithmic_bytes_per_step": hbm[hdom][2], "achieved": hbm[hdom][2] / (hbm[hdom][0] * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                 "unit": "GB/s", "frac": hbm[hdom][2] / (hbm[hdom][0] * 1e-3) / 1e9 / PEAK_HBM_GBS,
                 "note": "most time-consuming launch group off the matrix cores; algorithmic bytes (each tensor once) over the hipEvent time; "
-                        "8 TB/s spec, ~6.3 TB/s achievable (MI355X_MICROARCH.md); PMC FETCH/WRITE sizes per kernel: profiles/r03_hbm_kernels.md"},
+                        "8 TB/s spec, ~6.3 TB/s achievable (MI355X_MICROARCH.md); PMC FETCH/WRITE sizes per kernel: profiles/r04_hbm_kernels.md"},
             "latency_bound_launches": {"groups": sorted(tiny), "launches_per_step": sum(v[3] for v in tiny.values()), "ms_per_step": sum(v[0] for v in tiny.values())},
             "serial_step_ms": total_ms,
             "end_to_end": {"gflop_per_query": GFLOP_PER_QUERY[args.workload],
