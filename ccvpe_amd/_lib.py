@@ -171,6 +171,13 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own HIP runtime, and the library must bind to the runtime the process's device memory and streams come
+    # from.  Loaded before torch, libccvpe_hip.so pulls in the system runtime and ccvpe_create then sees no device
+    # (`python __graft_entry__.py smoke`: build() loads the library, smoke() imported torch afterwards).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     override = os.environ.get("CCVPE_LIB_PATH")   # diagnostics: load an alternative build of the same ABI
     if override:
         lib = C.CDLL(override)
