@@ -152,7 +152,8 @@ size_t ccvpe_workspace_bytes(ccvpe_handle h, int32_t batch, int32_t grd_h, int32
 int ccvpe_forward(ccvpe_handle h, const float* grd, int32_t grd_h, int32_t grd_w, const float* sat,
                   int32_t batch, const ccvpe_outputs* out, void* stream);
 
-/* Device-side test-loop post-processing on forward outputs: poses[B] is DEVICE memory. */
+/* Device-side test-loop post-processing on forward outputs: poses[B] is DEVICE memory.  batch <= 4096 per call; one call in flight per
+ * handle (the launch keeps per-sample partial results and ticket counters in a scratch buffer of the handle). */
 int ccvpe_postprocess(ccvpe_handle h, const float* heatmap, const float* ori, int32_t batch,
                       ccvpe_pose* poses, void* stream);
 /* The same five numbers per query as one float row - rows[B][5] = (index, prob, cos, sin, angle_deg), DEVICE memory: the 20-byte
